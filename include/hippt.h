@@ -1,0 +1,289 @@
+/* hippt.h — C ABI of the MI355X (gfx950) path-trace backend.
+ *
+ * This is the drop-in boundary for the reference's `--gpu` backend:
+ *     pub fn render(scene: &Scene) -> RgbaImage        (src/gpu_renderer.rs:11-13,
+ *                                                        sole caller src/main.rs:91)
+ * Everything the reference passes across that call (the loaded `Scene`,
+ * src/scene.rs:87-92) is marshalled into the POD tables below; everything it
+ * gets back (an 8-bit RGBA image, row 0 = top, alpha 255,
+ * src/gpu_renderer.rs:186-198) comes back through a caller-owned buffer.
+ *
+ * Conventions
+ *   - plain pointers and sizes, no C++/torch types; all structs are POD with
+ *     natural alignment (only 4-byte scalars, then pointers);
+ *   - every function returns 0 on success, non-zero on error; the message is
+ *     available from hippt_last_error() (thread-local). No exceptions cross
+ *     the ABI. The reference panics via `expect` (gpu_renderer.rs:78,86,171);
+ *     a host wrapper turns non-zero into the same abort-with-message;
+ *   - the caller owns every pointer passed in or out; the library copies
+ *     inputs and never frees caller memory;
+ *   - the arithmetic specification is the reference CPU renderer
+ *     (src/renderer.rs), not the WGSL shader.
+ */
+#ifndef HIPPT_H
+#define HIPPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPPT_OK 0
+#define HIPPT_ERR_INVALID 1   /* bad argument / inconsistent tables        */
+#define HIPPT_ERR_DEVICE 2    /* HIP runtime error (message has the code)   */
+#define HIPPT_ERR_IO 3        /* file / JSON / PNG error                    */
+#define HIPPT_ERR_LIMIT 4     /* size beyond a documented limit             */
+
+#define HIPPT_N_COUNTERS 16
+
+/* ---- scene tables ------------------------------------------------------ */
+
+/* src/material.rs:4-11 */
+typedef struct hippt_material {
+    float rgb[3];
+    float metallic;
+    float roughness;
+    float ior;
+    float volume_density;
+    float volume_anisotropy;
+} hippt_material;
+
+/* src/sphere.rs:9-15. `order` = index of the object in the scene's object
+ * list (src/scene.rs:124-151); it carries the first-minimum tie rule of
+ * `intersect_closest` (src/renderer.rs:359-361) across the two tables. */
+typedef struct hippt_sphere {
+    float center[3];
+    float radius;
+    uint32_t material; /* index into materials[] */
+    uint32_t order;
+    uint32_t in_focus; /* src/object.rs:19-24 */
+} hippt_sphere;
+
+/* src/plane.rs:8-16. `normal` = normalize(u x v) (src/scene.rs:139). */
+typedef struct hippt_plane {
+    float point[3];
+    float u[3];
+    float v[3];
+    float normal[3];
+    uint32_t material;
+    uint32_t order;
+    uint32_t in_focus;
+} hippt_plane;
+
+/* src/light.rs:4-9 */
+typedef struct hippt_light {
+    float pos[3];
+    float u[3];
+    float v[3];
+    float intensity[3];
+} hippt_light;
+
+/* Camera basis exactly as src/main.rs:44-51 derives it:
+ *   forward = normalize(look_at - pos); right = normalize(up x forward);
+ *   up = normalize(forward x right); aspect = w/h; scale = tan(fov/2).
+ * `focus` is the autofocus distance (src/renderer.rs:204-234), `aperture`
+ * the lens radius (src/algebra.rs:67-73). */
+typedef struct hippt_camera {
+    float pos[3];
+    float right[3];
+    float up[3];
+    float forward[3];
+    float aspect;
+    float scale;
+    float aperture;
+    float focus;
+} hippt_camera;
+
+typedef struct hippt_scene {
+    hippt_camera camera;
+    uint32_t width;   /* scene.render.width   (src/scene.rs:18) */
+    uint32_t height;  /* scene.render.height                      */
+    uint32_t samples; /* scene.render.samples = divisor of the final average */
+    uint32_t n_materials;
+    uint32_t n_spheres;
+    uint32_t n_planes;
+    uint32_t n_lights;
+    uint32_t reserved;
+    const hippt_material *materials;
+    const hippt_sphere *spheres;
+    const hippt_plane *planes;
+    const hippt_light *lights;
+} hippt_scene;
+
+/* flags */
+#define HIPPT_FLAG_COUNTERS 1u   /* run the event-counting variant          */
+#define HIPPT_FLAG_WAVEFRONT 2u  /* queue-based extend/shade/shadow pipeline */
+#define HIPPT_FLAG_BVH 4u        /* LBVH over the sphere table               */
+#define HIPPT_FLAG_NO_BVH 8u     /* force the brute-force object loop        */
+#define HIPPT_FLAG_TABLES_GLOBAL 16u /* read scene tables from global memory
+                                        (scalar loads) instead of staging in LDS */
+
+typedef struct hippt_options {
+    uint32_t sample_begin; /* first global sample index rendered by this call */
+    uint32_t sample_count; /* 0 = scene.samples - sample_begin                */
+    uint32_t max_depth;    /* 0 = 5 = MAX_DEPTH (src/renderer.rs:15)          */
+    uint32_t seed;         /* global RNG seed; stream = f(seed, pixel, sample)*/
+    uint32_t flags;
+    int32_t device;        /* HIP device ordinal (one-shot entry points)      */
+} hippt_options;
+
+/* Event counters (index into the uint64[HIPPT_N_COUNTERS] array); the
+ * algorithmic FLOP model of SURVEY.md §8(d) is a dot product with these. */
+enum {
+    HIPPT_C_PATHS = 0,
+    HIPPT_C_EXTEND_RAYS = 1,
+    HIPPT_C_EXTEND_HITS = 2,
+    HIPPT_C_SHADOW_RAYS = 3,
+    HIPPT_C_SHADOW_SPHERE_TESTS = 4, /* as executed (per-lane early out) */
+    HIPPT_C_SHADOW_PLANE_TESTS = 5,
+    HIPPT_C_NEE_VERTICES = 6,        /* opaque + scatter vertices */
+    HIPPT_C_LIT_EVALS = 7,           /* unoccluded, front-facing shadow samples */
+    HIPPT_C_DIFFUSE_LOBES = 8,
+    HIPPT_C_SPEC_LOBES = 9,
+    HIPPT_C_GLASS_VERTICES = 10,
+    HIPPT_C_MEDIUM_VERTICES = 11,
+    HIPPT_C_SCATTER_EVENTS = 12,
+    HIPPT_C_EXTEND_SPHERE_TESTS = 13,
+    HIPPT_C_EXTEND_PLANE_TESTS = 14,
+    HIPPT_C_RESERVED = 15
+};
+
+const char *hippt_last_error(void);
+
+/* ---- one-shot entry points (what the Rust `hip_renderer::render` binds) -- */
+
+/* Replaces gpu_renderer::render (src/gpu_renderer.rs:11-13). Renders
+ * scene.samples samples per pixel on opts->device, averages, applies ACES +
+ * gamma 1/2.2 + truncating u8 quantisation (src/renderer.rs:184-191) and
+ * writes width*height*4 bytes RGBA (alpha 255, row 0 = top). opts may be NULL.
+ * Zero lights is legal and renders black (CPU path, src/renderer.rs:31),
+ * unlike the wgpu backend's `expect` at gpu_renderer.rs:116. */
+int hippt_render_rgba8(const hippt_scene *scene, const hippt_options *opts,
+                       uint8_t *out_rgba);
+
+/* Same render, but returns the raw radiance SUMS over the rendered sample
+ * range as width*height*3 floats (RGB interleaved, row 0 = top): the
+ * analogue of `accumulated_color` (src/gpu_renderer.rs:104,175-179).
+ * counters may be NULL; filled only with HIPPT_FLAG_COUNTERS. */
+int hippt_render_accum_f32(const hippt_scene *scene, const hippt_options *opts,
+                           float *out_accum, uint64_t *counters);
+
+/* ---- resident-context entry points (bench, multi-GPU, repeated renders) -- */
+
+typedef struct hippt_context hippt_context;
+
+/* Creates a context on HIP device `device` (stream, counter buffer). */
+int hippt_create(int device, hippt_context **out_ctx);
+int hippt_destroy(hippt_context *ctx);
+
+/* Copies the scene tables to device memory (replaces the per-dispatch buffer
+ * creation of src/gpu_renderer.rs:243-275; done once, not per dispatch). */
+int hippt_set_scene(hippt_context *ctx, const hippt_scene *scene);
+
+/* Launches the trace kernels for samples [sample_begin, sample_begin+count)
+ * of every pixel and ADDS the radiance sums into d_accum (device pointer,
+ * width*height*3 floats, caller-zeroed). Asynchronous on `stream` (a
+ * hipStream_t, NULL = the context's own stream). This is the hot path
+ * (src/renderer.rs:163-182 + 237-353 for every pixel). */
+int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts,
+                              float *d_accum, void *stream);
+
+/* Average / ACES / gamma / quantise on the device (src/renderer.rs:184-191):
+ * d_accum (sums) / spp -> d_rgba (width*height*4 bytes). */
+int hippt_resolve_device(hippt_context *ctx, const float *d_accum, uint32_t spp,
+                         uint8_t *d_rgba, void *stream);
+
+/* Waits for the context's stream and copies out the event counters
+ * accumulated since the last call (then zeroes them). */
+int hippt_read_counters(hippt_context *ctx, uint64_t *counters);
+
+/* Average duration in ms of the trace-kernel launches issued through this
+ * context since the last call (HIP events on the launch stream), and their
+ * number. Synchronises the stream. */
+int hippt_kernel_time_ms(hippt_context *ctx, double *total_ms, uint32_t *launches);
+
+/* ---- host-side scene plumbing (src/scene.rs, src/main.rs) ---------------- */
+
+typedef struct hippt_scene_file hippt_scene_file; /* owns the tables */
+
+/* Parses a scene.json (schema: src/scene.rs:6-84), resolves materials by name
+ * with the magenta default (src/scene.rs:112-128), precomputes plane normals
+ * (:139), derives the camera basis (src/main.rs:44-51) and the autofocus
+ * distance (src/renderer.rs:204-234). */
+int hippt_scene_load(const char *path, hippt_scene_file **out);
+int hippt_scene_parse(const char *json_text, size_t len, hippt_scene_file **out);
+const hippt_scene *hippt_scene_get(const hippt_scene_file *f);
+/* Overrides render.width/height/samples and re-derives aspect and autofocus. */
+int hippt_scene_set_render(hippt_scene_file *f, uint32_t width, uint32_t height,
+                           uint32_t samples);
+void hippt_scene_free(hippt_scene_file *f);
+
+/* Camera basis from pos/look_at/up/fov(deg) as src/main.rs:41-51. */
+void hippt_camera_basis(const float pos[3], const float look_at[3], const float up[3],
+                        float fov_deg, uint32_t width, uint32_t height,
+                        hippt_camera *out);
+/* src/renderer.rs:204-234 (5x5 probe rays over in_focus objects). */
+float hippt_autofocus(const hippt_scene *scene);
+
+/* `renders/render_{w}x{h}_s{s}_ap{ap:.2}_f{f:.1}_{6 alnum}.png`
+ * (src/renderer.rs:156-161). Returns the length written (excluding NUL). */
+int hippt_render_image_name(uint32_t w, uint32_t h, uint32_t s, float ap, float f,
+                            char *out, size_t cap);
+/* 8-bit RGBA PNG (what `RgbaImage::save` produces, src/main.rs:104). */
+int hippt_write_png_rgba8(const char *path, const uint8_t *rgba, uint32_t w, uint32_t h);
+
+/* ---- unit-kernel test exports (1e-5 parity clause; no reference analogue) --
+ * Each runs a HIP kernel over n independent inputs (host pointers in/out,
+ * arrays of n items, vec3 = 3 consecutive floats). */
+
+/* intersect_closest (src/renderer.rs:356-362) over the scene's objects.
+ * out_index = object `order` of the hit, -1 on miss; t = +inf on miss. */
+int hippt_test_intersect(const hippt_scene *scene, uint32_t n, const float *ro,
+                         const float *rd, float *out_t, float *out_normal,
+                         int32_t *out_index, int device);
+/* LBVH closest hit (same outputs; requires a prior build over the scene). */
+int hippt_test_intersect_bvh(const hippt_scene *scene, uint32_t n, const float *ro,
+                             const float *rd, float *out_t, float *out_normal,
+                             int32_t *out_index, int device);
+/* shadow test of src/renderer.rs:46: any hit with t*t < dist2*0.999. */
+int hippt_test_occluded(const hippt_scene *scene, uint32_t n, const float *ro,
+                        const float *rd, const float *dist2, uint8_t *out, int device);
+/* one unoccluded light sample, src/renderer.rs:49-77. mat = n x 8 floats in
+ * hippt_material order; light = one hippt_light. out = rgb contribution
+ * (before the 1/SHADOW_SAMPLES average). */
+int hippt_test_nee_eval(uint32_t n, const float *nrm, const float *v, const float *l,
+                        const float *dist2, const float *mat, const hippt_light *light,
+                        float *out_rgb, int device);
+/* src/ggx.rs:7-18: out = {F.r, F.g, F.b, D, G} per item. */
+int hippt_test_ggx_terms(uint32_t n, const float *nh, const float *nv, const float *nl,
+                         const float *vh, const float *rough, const float *f0,
+                         float *out5, int device);
+/* src/ggx.rs:20-45 with explicit uniforms r1,r2. */
+int hippt_test_ggx_sample(uint32_t n, const float *nrm, const float *rough,
+                          const float *r1, const float *r2, float *out_h, int device);
+/* src/renderer.rs:330-335 with explicit uniforms (u_phi, r2). */
+int hippt_test_diffuse_sample(uint32_t n, const float *nrm, const float *u_phi,
+                              const float *r2, float *out_dir, int device);
+/* src/renderer.rs:309-317 + refract :364-369; rd = incoming direction (-v),
+ * nrm = hit normal, u = the uniform of :315. out_dir = next direction. */
+int hippt_test_glass(uint32_t n, const float *rd, const float *nrm, const float *ior,
+                     const float *u, float *out_dir, int device);
+/* src/renderer.rs:194-202 and the scatter frame :276-282.
+ * out4 = {cos_theta, dir.x, dir.y, dir.z}. */
+int hippt_test_hg(uint32_t n, const float *rd, const float *g, const float *u_hg,
+                  const float *u_phi, float *out4, int device);
+/* src/renderer.rs:170-178 + src/algebra.rs:67-73; u4 = {jx, jy, s, t}. */
+int hippt_test_camera_ray(const hippt_scene *scene, uint32_t n, const uint32_t *xy,
+                          const float *u4, float *out_ro, float *out_rd, int device);
+/* src/tonemap.rs:10-19 + src/renderer.rs:187-191 on mean radiance. */
+int hippt_test_tonemap(uint32_t n, const float *rgb, uint8_t *out_rgb8, int device);
+/* first `n` uniforms of the stream (seed, pixel, sample): DESIGN.md §RNG. */
+int hippt_test_rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t n,
+                   float *out, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPPT_H */

@@ -1,0 +1,572 @@
+// hippt_api.hip — C ABI (include/hippt.h) over the gfx950 kernels.
+//
+// Replaces the host half of the reference's wgpu backend
+// (src/gpu_renderer.rs:76-200): device setup, table packing, dispatch sizing,
+// accumulation and the final average/tonemap, for the HIP kernels in
+// pt_kernels.hip. There is no CPU fallback: every entry point needs a HIP
+// device and fails with HIPPT_ERR_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hippt.h"
+#include "hippt_internal.h"
+#include "pt_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+}  // namespace
+
+int hippt_set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return hippt_set_error(HIPPT_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                   __FILE__, __LINE__);                                            \
+    } while (0)
+
+namespace {
+
+// Paths per launch: bounds one launch to a fraction of a second so that long
+// renders stay observable (analogue of the 600 M budget, gpu_renderer.rs:94).
+constexpr uint64_t kPathsPerLaunch = 4ull << 30;
+// LDS budget for the staged tables (default dynamic LDS limit per block).
+constexpr size_t kMaxLdsBlob = 60 * 1024;
+
+struct PackedScene {
+    pt::Params P{};
+    std::vector<float4> blob;
+};
+
+float4 mk4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+float as_f(uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// Table packing: the counterpart of get_object_data (gpu_renderer.rs:203-223),
+// without its 32+32 object cap and with volumes and every light kept.
+int pack_scene(const hippt_scene *sc, PackedScene &out) {
+    if (!sc) return hippt_set_error(HIPPT_ERR_INVALID, "scene is NULL");
+    if (sc->width == 0 || sc->height == 0) return hippt_set_error(HIPPT_ERR_INVALID, "empty image %ux%u", sc->width, sc->height);
+    if ((uint64_t)sc->width * sc->height > (1ull << 31))
+        return hippt_set_error(HIPPT_ERR_LIMIT, "image %ux%u exceeds 2^31 pixels", sc->width, sc->height);
+    uint32_t n_obj = sc->n_spheres + sc->n_planes;
+    if ((sc->n_spheres && !sc->spheres) || (sc->n_planes && !sc->planes) || (sc->n_lights && !sc->lights) ||
+        (sc->n_materials && !sc->materials))
+        return hippt_set_error(HIPPT_ERR_INVALID, "NULL table with non-zero count");
+    pt::Params &P = out.P;
+    const hippt_camera &c = sc->camera;
+    std::memcpy(P.cam_pos, c.pos, 12);
+    std::memcpy(P.cam_right, c.right, 12);
+    std::memcpy(P.cam_up, c.up, 12);
+    std::memcpy(P.cam_fwd, c.forward, 12);
+    P.aspect = c.aspect;
+    P.scale = c.scale;
+    P.aperture = c.aperture;
+    P.focus = c.focus;
+    P.width = sc->width;
+    P.height = sc->height;
+    P.inv_w = 1.0f / (float)sc->width;
+    P.inv_h = 1.0f / (float)sc->height;
+    P.n_obj = n_obj;
+    P.n_mat = sc->n_materials;
+    P.n_light = sc->n_lights;
+    P.mat_off = n_obj * pt::OBJ_F4;
+    P.light_off = P.mat_off + sc->n_materials * pt::MAT_F4;
+    P.blob_f4 = P.light_off + sc->n_lights * pt::LIGHT_F4;
+    P.tiles_x = (sc->width + 15u) / 16u;
+    out.blob.assign(P.blob_f4 ? P.blob_f4 : 1, mk4(0, 0, 0, 0));
+
+    std::vector<char> seen(n_obj, 0);
+    for (uint32_t i = 0; i < sc->n_spheres; ++i) {
+        const hippt_sphere &s = sc->spheres[i];
+        if (s.order >= n_obj || seen[s.order]) return hippt_set_error(HIPPT_ERR_INVALID, "sphere %u: bad order %u", i, s.order);
+        if (s.material >= sc->n_materials) return hippt_set_error(HIPPT_ERR_INVALID, "sphere %u: bad material %u", i, s.material);
+        seen[s.order] = 1;
+        float4 *q = &out.blob[(size_t)s.order * pt::OBJ_F4];
+        q[0] = mk4(s.center[0], s.center[1], s.center[2], s.radius * s.radius);
+        q[1] = mk4(1.0f / s.radius, s.radius, 0, 0);
+        q[2] = mk4(0, 0, 0, 0);
+        q[3] = mk4(0, 0, as_f(s.material), as_f(0u));
+    }
+    for (uint32_t i = 0; i < sc->n_planes; ++i) {
+        const hippt_plane &p = sc->planes[i];
+        if (p.order >= n_obj || seen[p.order]) return hippt_set_error(HIPPT_ERR_INVALID, "plane %u: bad order %u", i, p.order);
+        if (p.material >= sc->n_materials) return hippt_set_error(HIPPT_ERR_INVALID, "plane %u: bad material %u", i, p.material);
+        seen[p.order] = 1;
+        float uu = p.u[0] * p.u[0] + p.u[1] * p.u[1] + p.u[2] * p.u[2];  // plane.rs:45
+        float vv = p.v[0] * p.v[0] + p.v[1] * p.v[1] + p.v[2] * p.v[2];  // plane.rs:50
+        float4 *q = &out.blob[(size_t)p.order * pt::OBJ_F4];
+        q[0] = mk4(p.point[0], p.point[1], p.point[2], uu);
+        q[1] = mk4(p.normal[0], p.normal[1], p.normal[2], vv);
+        q[2] = mk4(p.u[0], p.u[1], p.u[2], p.v[0]);
+        q[3] = mk4(p.v[1], p.v[2], as_f(p.material), as_f(1u));
+    }
+    for (uint32_t i = 0; i < sc->n_materials; ++i) {
+        const hippt_material &m = sc->materials[i];
+        float4 *q = &out.blob[P.mat_off + (size_t)i * pt::MAT_F4];
+        q[0] = mk4(m.rgb[0], m.rgb[1], m.rgb[2], m.metallic);
+        q[1] = mk4(m.roughness, m.ior, m.volume_density, m.volume_anisotropy);
+    }
+    for (uint32_t i = 0; i < sc->n_lights; ++i) {
+        const hippt_light &l = sc->lights[i];
+        // renderer.rs:51-52, hoisted: area = |u x v|, normal = normalize(u x v)
+        float cx = l.u[1] * l.v[2] - l.u[2] * l.v[1];
+        float cy = l.u[2] * l.v[0] - l.u[0] * l.v[2];
+        float cz = l.u[0] * l.v[1] - l.u[1] * l.v[0];
+        float area = std::sqrt(cx * cx + cy * cy + cz * cz);
+        float inv = 1.0f / area;
+        float4 *q = &out.blob[P.light_off + (size_t)i * pt::LIGHT_F4];
+        q[0] = mk4(l.pos[0], l.pos[1], l.pos[2], area);
+        q[1] = mk4(l.u[0], l.u[1], l.u[2], 0);
+        q[2] = mk4(l.v[0], l.v[1], l.v[2], 0);
+        q[3] = mk4(l.intensity[0], l.intensity[1], l.intensity[2], 0);
+        q[4] = mk4(cx * inv, cy * inv, cz * inv, 0);
+    }
+    return HIPPT_OK;
+}
+
+}  // namespace
+
+struct hippt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    PackedScene scene;
+    bool has_scene = false;
+    float4 *d_blob = nullptr;
+    size_t d_blob_cap = 0;
+    unsigned long long *d_counters = nullptr;
+    uint32_t samples = 0;
+    // kernel timing (events on the launch stream)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+};
+
+extern "C" {
+
+const char *hippt_last_error(void) { return g_err; }
+
+int hippt_create(int device, hippt_context **out_ctx) {
+    if (!out_ctx) return hippt_set_error(HIPPT_ERR_INVALID, "out_ctx is NULL");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return hippt_set_error(HIPPT_ERR_DEVICE, "HIP device %d not present (%d devices)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hippt_context *ctx = new hippt_context();
+    ctx->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_counters, HIPPT_N_COUNTERS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, HIPPT_N_COUNTERS * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        hippt_destroy(ctx);
+        return hippt_set_error(HIPPT_ERR_DEVICE, "context setup failed: %s", hipGetErrorString(e));
+    }
+    *out_ctx = ctx;
+    return HIPPT_OK;
+}
+
+int hippt_destroy(hippt_context *ctx) {
+    if (!ctx) return HIPPT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->ev_pool) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    if (ctx->d_blob) (void)hipFree(ctx->d_blob);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return HIPPT_OK;
+}
+
+int hippt_set_scene(hippt_context *ctx, const hippt_scene *scene) {
+    if (!ctx) return hippt_set_error(HIPPT_ERR_INVALID, "ctx is NULL");
+    PackedScene ps;
+    int rc = pack_scene(scene, ps);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t bytes = ps.blob.size() * sizeof(float4);
+    if (bytes > ctx->d_blob_cap) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_blob) HIP_TRY(hipFree(ctx->d_blob));
+        ctx->d_blob = nullptr;
+        ctx->d_blob_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->d_blob, bytes));
+        ctx->d_blob_cap = bytes;
+    }
+    HIP_TRY(hipMemcpy(ctx->d_blob, ps.blob.data(), bytes, hipMemcpyHostToDevice));
+    ctx->scene = std::move(ps);
+    ctx->samples = scene->samples;
+    ctx->has_scene = true;
+    return HIPPT_OK;
+}
+
+int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, float *d_accum, void *stream) {
+    if (!ctx || !ctx->has_scene) return hippt_set_error(HIPPT_ERR_INVALID, "no scene set");
+    if (!d_accum) return hippt_set_error(HIPPT_ERR_INVALID, "d_accum is NULL");
+    hippt_options o{};
+    if (opts) o = *opts;
+    uint32_t s0 = o.sample_begin;
+    uint32_t cnt = o.sample_count ? o.sample_count : (ctx->samples > s0 ? ctx->samples - s0 : 0);
+    if ((uint64_t)s0 + cnt > 0xffffffffull) return hippt_set_error(HIPPT_ERR_LIMIT, "sample range overflows 32 bits");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    pt::Params P = ctx->scene.P;
+    P.max_depth = o.max_depth ? o.max_depth : 5u;  // MAX_DEPTH, renderer.rs:15
+    P.seed = o.seed;
+    bool count = (o.flags & HIPPT_FLAG_COUNTERS) != 0;
+    bool lds = (size_t)P.blob_f4 * sizeof(float4) <= kMaxLdsBlob;
+    if (o.flags & HIPPT_FLAG_TABLES_GLOBAL) lds = false;
+    uint64_t pixels = (uint64_t)P.width * P.height;
+    uint64_t per = kPathsPerLaunch / pixels;
+    if (per < 1) per = 1;
+    while (cnt > 0) {
+        uint32_t c = (uint32_t)std::min<uint64_t>(cnt, per);
+        P.sample_begin = s0;
+        P.sample_count = c;
+        // time each launch with events on the stream it runs on
+        if (ctx->ev_used == ctx->ev_pool.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            ctx->ev_pool.emplace_back(a, b);
+        }
+        auto &ev = ctx->ev_pool[ctx->ev_used++];
+        HIP_TRY(hipEventRecord(ev.first, st));
+        HIP_TRY(pt::launch_megakernel(P, ctx->d_blob, d_accum, ctx->d_counters, count, lds, st));
+        HIP_TRY(hipEventRecord(ev.second, st));
+        s0 += c;
+        cnt -= c;
+    }
+    return HIPPT_OK;
+}
+
+int hippt_resolve_device(hippt_context *ctx, const float *d_accum, uint32_t spp, uint8_t *d_rgba, void *stream) {
+    if (!ctx || !ctx->has_scene) return hippt_set_error(HIPPT_ERR_INVALID, "no scene set");
+    if (!d_accum || !d_rgba || spp == 0) return hippt_set_error(HIPPT_ERR_INVALID, "bad resolve arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(pt::launch_resolve(d_accum, ctx->scene.P.width * ctx->scene.P.height, spp, d_rgba, st));
+    return HIPPT_OK;
+}
+
+int hippt_read_counters(hippt_context *ctx, uint64_t *counters) {
+    if (!ctx || !counters) return hippt_set_error(HIPPT_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(counters, ctx->d_counters, HIPPT_N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(ctx->d_counters, 0, HIPPT_N_COUNTERS * sizeof(uint64_t)));
+    return HIPPT_OK;
+}
+
+int hippt_kernel_time_ms(hippt_context *ctx, double *total_ms, uint32_t *launches) {
+    if (!ctx) return hippt_set_error(HIPPT_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    double tot = 0;
+    for (size_t i = 0; i < ctx->ev_used; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_pool[i].first, ctx->ev_pool[i].second));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (uint32_t)ctx->ev_used;
+    ctx->ev_used = 0;
+    return HIPPT_OK;
+}
+
+int hippt_render_accum_f32(const hippt_scene *scene, const hippt_options *opts, float *out_accum, uint64_t *counters) {
+    if (!scene || !out_accum) return hippt_set_error(HIPPT_ERR_INVALID, "NULL argument");
+    hippt_context *ctx = nullptr;
+    int rc = hippt_create(opts ? opts->device : 0, &ctx);
+    if (rc) return rc;
+    float *d_accum = nullptr;
+    size_t bytes = (size_t)scene->width * scene->height * 3 * sizeof(float);
+    auto fail = [&](int code) {
+        if (d_accum) (void)hipFree(d_accum);
+        hippt_destroy(ctx);
+        return code;
+    };
+    rc = hippt_set_scene(ctx, scene);
+    if (rc) return fail(rc);
+    if (hipMalloc(&d_accum, bytes) != hipSuccess) return fail(hippt_set_error(HIPPT_ERR_DEVICE, "hipMalloc(%zu) failed", bytes));
+    if (hipMemsetAsync(d_accum, 0, bytes, ctx->stream) != hipSuccess) return fail(hippt_set_error(HIPPT_ERR_DEVICE, "memset failed"));
+    rc = hippt_render_accum_device(ctx, opts, d_accum, nullptr);
+    if (rc) return fail(rc);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out_accum, d_accum, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(hippt_set_error(HIPPT_ERR_DEVICE, "render failed: %s", hipGetErrorString(e)));
+    if (counters) {
+        rc = hippt_read_counters(ctx, counters);
+        if (rc) return fail(rc);
+    }
+    return fail(HIPPT_OK);
+}
+
+int hippt_render_rgba8(const hippt_scene *scene, const hippt_options *opts, uint8_t *out_rgba) {
+    if (!scene || !out_rgba) return hippt_set_error(HIPPT_ERR_INVALID, "NULL argument");
+    if (scene->samples == 0) return hippt_set_error(HIPPT_ERR_INVALID, "render.samples is 0");
+    hippt_context *ctx = nullptr;
+    int rc = hippt_create(opts ? opts->device : 0, &ctx);
+    if (rc) return rc;
+    float *d_accum = nullptr;
+    uint8_t *d_rgba = nullptr;
+    size_t npx = (size_t)scene->width * scene->height;
+    auto fail = [&](int code) {
+        if (d_accum) (void)hipFree(d_accum);
+        if (d_rgba) (void)hipFree(d_rgba);
+        hippt_destroy(ctx);
+        return code;
+    };
+    rc = hippt_set_scene(ctx, scene);
+    if (rc) return fail(rc);
+    if (hipMalloc(&d_accum, npx * 12) != hipSuccess || hipMalloc(&d_rgba, npx * 4) != hipSuccess)
+        return fail(hippt_set_error(HIPPT_ERR_DEVICE, "hipMalloc failed for %zu pixels", npx));
+    if (hipMemsetAsync(d_accum, 0, npx * 12, ctx->stream) != hipSuccess) return fail(hippt_set_error(HIPPT_ERR_DEVICE, "memset failed"));
+    hippt_options o{};
+    if (opts) o = *opts;
+    o.sample_begin = 0;
+    o.sample_count = scene->samples;
+    rc = hippt_render_accum_device(ctx, &o, d_accum, nullptr);
+    if (rc) return fail(rc);
+    rc = hippt_resolve_device(ctx, d_accum, scene->samples, d_rgba, nullptr);
+    if (rc) return fail(rc);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out_rgba, d_rgba, npx * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(hippt_set_error(HIPPT_ERR_DEVICE, "render failed: %s", hipGetErrorString(e)));
+    return fail(HIPPT_OK);
+}
+
+}  // extern "C"
+
+// ---- unit-kernel test exports ------------------------------------------------------
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 4); }
+    template <class T>
+    T *as() { return (T *)p; }
+};
+hipError_t up(DevBuf &b, const void *src, size_t bytes) {
+    hipError_t e = b.alloc(bytes);
+    if (e != hipSuccess) return e;
+    return bytes ? hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+}
+int use_device(int device) {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return hippt_set_error(HIPPT_ERR_DEVICE, "HIP device %d not present (%d devices)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    return HIPPT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+#define UP(buf, src, bytes) HIP_TRY(up(buf, src, bytes))
+#define DOWN(dst, buf, bytes)                                        \
+    do {                                                             \
+        HIP_TRY(hipDeviceSynchronize());                             \
+        HIP_TRY(hipMemcpy(dst, (buf).p, bytes, hipMemcpyDeviceToHost)); \
+    } while (0)
+
+int hippt_test_intersect(const hippt_scene *scene, uint32_t n, const float *ro, const float *rd, float *out_t,
+                         float *out_normal, int32_t *out_index, int device) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    PackedScene ps;
+    rc = pack_scene(scene, ps);
+    if (rc) return rc;
+    if (ps.blob.size() * 16 > kMaxLdsBlob) return hippt_set_error(HIPPT_ERR_LIMIT, "scene tables exceed the LDS budget of the unit kernel");
+    DevBuf blob, dro, drd, dt, dn, di;
+    UP(blob, ps.blob.data(), ps.blob.size() * 16);
+    UP(dro, ro, (size_t)n * 12);
+    UP(drd, rd, (size_t)n * 12);
+    HIP_TRY(dt.alloc((size_t)n * 4));
+    HIP_TRY(dn.alloc((size_t)n * 12));
+    HIP_TRY(di.alloc((size_t)n * 4));
+    if (n) HIP_TRY(pt::launch_unit_intersect(ps.P, blob.as<float4>(), n, dro.as<float>(), drd.as<float>(), dt.as<float>(), dn.as<float>(), di.as<int32_t>(), nullptr));
+    DOWN(out_t, dt, (size_t)n * 4);
+    DOWN(out_normal, dn, (size_t)n * 12);
+    DOWN(out_index, di, (size_t)n * 4);
+    return HIPPT_OK;
+}
+
+int hippt_test_occluded(const hippt_scene *scene, uint32_t n, const float *ro, const float *rd, const float *dist2,
+                        uint8_t *out, int device) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    PackedScene ps;
+    rc = pack_scene(scene, ps);
+    if (rc) return rc;
+    if (ps.blob.size() * 16 > kMaxLdsBlob) return hippt_set_error(HIPPT_ERR_LIMIT, "scene tables exceed the LDS budget of the unit kernel");
+    DevBuf blob, dro, drd, dd, dout;
+    UP(blob, ps.blob.data(), ps.blob.size() * 16);
+    UP(dro, ro, (size_t)n * 12);
+    UP(drd, rd, (size_t)n * 12);
+    UP(dd, dist2, (size_t)n * 4);
+    HIP_TRY(dout.alloc(n));
+    if (n) HIP_TRY(pt::launch_unit_occluded(ps.P, blob.as<float4>(), n, dro.as<float>(), drd.as<float>(), dd.as<float>(), dout.as<uint8_t>(), nullptr));
+    DOWN(out, dout, n);
+    return HIPPT_OK;
+}
+
+int hippt_test_nee_eval(uint32_t n, const float *nrm, const float *v, const float *l, const float *dist2,
+                        const float *mat, const hippt_light *light, float *out_rgb, int device) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (!light) return hippt_set_error(HIPPT_ERR_INVALID, "light is NULL");
+    DevBuf dn, dv, dl, dd, dm, dout;
+    UP(dn, nrm, (size_t)n * 12);
+    UP(dv, v, (size_t)n * 12);
+    UP(dl, l, (size_t)n * 12);
+    UP(dd, dist2, (size_t)n * 4);
+    UP(dm, mat, (size_t)n * 32);
+    HIP_TRY(dout.alloc((size_t)n * 12));
+    if (n) HIP_TRY(pt::launch_unit_nee_eval(n, dn.as<float>(), dv.as<float>(), dl.as<float>(), dd.as<float>(), dm.as<float>(), *light, dout.as<float>(), nullptr));
+    DOWN(out_rgb, dout, (size_t)n * 12);
+    return HIPPT_OK;
+}
+
+int hippt_test_ggx_terms(uint32_t n, const float *nh, const float *nv, const float *nl, const float *vh,
+                         const float *rough, const float *f0, float *out5, int device) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBuf a, b, c, d, e, f, o;
+    UP(a, nh, (size_t)n * 4);
+    UP(b, nv, (size_t)n * 4);
+    UP(c, nl, (size_t)n * 4);
+    UP(d, vh, (size_t)n * 4);
+    UP(e, rough, (size_t)n * 4);
+    UP(f, f0, (size_t)n * 12);
+    HIP_TRY(o.alloc((size_t)n * 20));
+    if (n) HIP_TRY(pt::launch_unit_ggx_terms(n, a.as<float>(), b.as<float>(), c.as<float>(), d.as<float>(), e.as<float>(), f.as<float>(), o.as<float>(), nullptr));
+    DOWN(out5, o, (size_t)n * 20);
+    return HIPPT_OK;
+}
+
+int hippt_test_ggx_sample(uint32_t n, const float *nrm, const float *rough, const float *r1, const float *r2,
+                          float *out_h, int device) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBuf a, b, c, d, o;
+    UP(a, nrm, (size_t)n * 12);
+    UP(b, rough, (size_t)n * 4);
+    UP(c, r1, (size_t)n * 4);
+    UP(d, r2, (size_t)n * 4);
+    HIP_TRY(o.alloc((size_t)n * 12));
+    if (n) HIP_TRY(pt::launch_unit_ggx_sample(n, a.as<float>(), b.as<float>(), c.as<float>(), d.as<float>(), o.as<float>(), nullptr));
+    DOWN(out_h, o, (size_t)n * 12);
+    return HIPPT_OK;
+}
+
+int hippt_test_diffuse_sample(uint32_t n, const float *nrm, const float *u_phi, const float *r2, float *out_dir,
+                              int device) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBuf a, b, c, o;
+    UP(a, nrm, (size_t)n * 12);
+    UP(b, u_phi, (size_t)n * 4);
+    UP(c, r2, (size_t)n * 4);
+    HIP_TRY(o.alloc((size_t)n * 12));
+    if (n) HIP_TRY(pt::launch_unit_diffuse(n, a.as<float>(), b.as<float>(), c.as<float>(), o.as<float>(), nullptr));
+    DOWN(out_dir, o, (size_t)n * 12);
+    return HIPPT_OK;
+}
+
+int hippt_test_glass(uint32_t n, const float *rd, const float *nrm, const float *ior, const float *u, float *out_dir,
+                     int device) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBuf a, b, c, d, o;
+    UP(a, rd, (size_t)n * 12);
+    UP(b, nrm, (size_t)n * 12);
+    UP(c, ior, (size_t)n * 4);
+    UP(d, u, (size_t)n * 4);
+    HIP_TRY(o.alloc((size_t)n * 12));
+    if (n) HIP_TRY(pt::launch_unit_glass(n, a.as<float>(), b.as<float>(), c.as<float>(), d.as<float>(), o.as<float>(), nullptr));
+    DOWN(out_dir, o, (size_t)n * 12);
+    return HIPPT_OK;
+}
+
+int hippt_test_hg(uint32_t n, const float *rd, const float *g, const float *u_hg, const float *u_phi, float *out4,
+                  int device) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBuf a, b, c, d, o;
+    UP(a, rd, (size_t)n * 12);
+    UP(b, g, (size_t)n * 4);
+    UP(c, u_hg, (size_t)n * 4);
+    UP(d, u_phi, (size_t)n * 4);
+    HIP_TRY(o.alloc((size_t)n * 16));
+    if (n) HIP_TRY(pt::launch_unit_hg(n, a.as<float>(), b.as<float>(), c.as<float>(), d.as<float>(), o.as<float>(), nullptr));
+    DOWN(out4, o, (size_t)n * 16);
+    return HIPPT_OK;
+}
+
+int hippt_test_camera_ray(const hippt_scene *scene, uint32_t n, const uint32_t *xy, const float *u4, float *out_ro,
+                          float *out_rd, int device) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    PackedScene ps;
+    rc = pack_scene(scene, ps);
+    if (rc) return rc;
+    DevBuf a, b, o1, o2;
+    UP(a, xy, (size_t)n * 8);
+    UP(b, u4, (size_t)n * 16);
+    HIP_TRY(o1.alloc((size_t)n * 12));
+    HIP_TRY(o2.alloc((size_t)n * 12));
+    if (n) HIP_TRY(pt::launch_unit_camera(ps.P, n, a.as<uint32_t>(), b.as<float>(), o1.as<float>(), o2.as<float>(), nullptr));
+    DOWN(out_ro, o1, (size_t)n * 12);
+    DOWN(out_rd, o2, (size_t)n * 12);
+    return HIPPT_OK;
+}
+
+int hippt_test_tonemap(uint32_t n, const float *rgb, uint8_t *out_rgb8, int device) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBuf a, o;
+    UP(a, rgb, (size_t)n * 12);
+    HIP_TRY(o.alloc((size_t)n * 3));
+    if (n) HIP_TRY(pt::launch_unit_tonemap(n * 3, a.as<float>(), o.as<uint8_t>(), nullptr));
+    DOWN(out_rgb8, o, (size_t)n * 3);
+    return HIPPT_OK;
+}
+
+int hippt_test_rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float *out, int device) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBuf o;
+    HIP_TRY(o.alloc((size_t)n * 4));
+    if (n) HIP_TRY(pt::launch_unit_rng(seed, pixel, sample, n, o.as<float>(), nullptr));
+    DOWN(out, o, (size_t)n * 4);
+    return HIPPT_OK;
+}
+
+int hippt_test_intersect_bvh(const hippt_scene *, uint32_t, const float *, const float *, float *, float *, int32_t *,
+                             int) {
+    return hippt_set_error(HIPPT_ERR_INVALID, "LBVH path not built in this version");
+}
+
+}  // extern "C"

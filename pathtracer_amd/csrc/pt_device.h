@@ -1,0 +1,390 @@
+// pt_device.h — device-side math of the gfx950 path-trace kernels.
+//
+// Written from the behaviour of the reference CPU renderer
+// (eliasstepanik/Pathtracer src/renderer.rs, ggx.rs, sphere.rs, plane.rs,
+// algebra.rs, tonemap.rs); each function cites the lines whose result it must
+// reproduce. The code is free to re-associate and fuse (FMA contraction, fast
+// v_rcp/v_rsq/v_sqrt/v_sin/v_cos/v_log/v_exp) as long as results stay within
+// the 1e-5 relative parity bound; per-ray and per-light invariants are hoisted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hippt.h"
+
+namespace pt {
+
+// ---- scene blob layout (float4 units), built by hippt_api.hip ---------------
+//   objects : n_obj  x 4   in scene order (tie rule of renderer.rs:359-361)
+//     sphere : {cx,cy,cz,r*r} {1/r, r, 0, 0} {0,0,0,0}    {0, 0, mat, kind=0}
+//     plane  : {px,py,pz,u.u} {nx,ny,nz,v.v} {ux,uy,uz,vx} {vy,vz, mat, kind=1}
+//   materials : n_mat x 2  {r,g,b,metallic} {roughness,ior,density,anisotropy}
+//   lights    : n_light x 5 {pos,area} {u,0} {v,0} {intensity,0} {normal,0}
+constexpr int OBJ_F4 = 4;
+constexpr int MAT_F4 = 2;
+constexpr int LIGHT_F4 = 5;
+
+struct Params {
+    float cam_pos[3];
+    float cam_right[3];
+    float cam_up[3];
+    float cam_fwd[3];
+    float aspect, scale, aperture, focus;
+    uint32_t width, height;
+    float inv_w, inv_h;
+    uint32_t n_obj, n_mat, n_light;
+    uint32_t mat_off, light_off;  // float4 offsets into the blob
+    uint32_t blob_f4;             // blob size in float4
+    uint32_t sample_begin, sample_count, max_depth, seed;
+    uint32_t tiles_x;             // 16x16 pixel tiles per row
+};
+
+// ---- float3 -------------------------------------------------------------------
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 f3(float4 v) { return F3{v.x, v.y, v.z}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return F3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return F3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ F3 operator-(F3 a) { return F3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ F3 cross(F3 a, F3 b) {
+    return F3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// a + b*s
+__device__ __forceinline__ F3 madd(F3 a, F3 b, float s) {
+    return F3{fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z)};
+}
+
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+// sin / cos of 2*pi*rev (v_sin_f32 / v_cos_f32 take revolutions)
+__device__ __forceinline__ float sin2pi(float rev) { return __builtin_amdgcn_sinf(rev); }
+__device__ __forceinline__ float cos2pi(float rev) { return __builtin_amdgcn_cosf(rev); }
+__device__ __forceinline__ float fln(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
+// algebra.rs:19  self.scale(1.0/self.norm())
+__device__ __forceinline__ F3 normalize(F3 a) { return a * rsq(dot(a, a)); }
+// algebra.rs:21-27
+__device__ __forceinline__ F3 any_orthonormal(F3 a) {
+    return (fabsf(a.z) < 0.9999999f) ? F3{a.y, -a.x, 0.0f} : F3{0.0f, -a.z, a.y};
+}
+// f32::clamp (NaN passes through)
+__device__ __forceinline__ float rclamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+__device__ __forceinline__ float pow5(float x) {
+    float x2 = x * x;
+    return x * (x2 * x2);
+}
+
+// ---- uniform stream -------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+struct Rng {
+    uint32_t s0, s1;
+    __device__ __forceinline__ void seed(uint32_t seed_mixed, uint32_t pixel_mixed_base, uint32_t sample) {
+        // seed_mixed = mix32(seed ^ 0x85ebca6b) and pixel_mixed_base = mix32(pixel + seed_mixed)
+        // are per-launch / per-pixel invariants, hoisted by the caller.
+        (void)seed_mixed;
+        uint32_t c = mix32(sample ^ pixel_mixed_base);
+        s0 = c;
+        s1 = mix32(c + 0x9e3779b9u) | 1u;
+    }
+    __device__ __forceinline__ float gen() {
+        uint32_t r = s0 + s1;
+        uint32_t t = s1 ^ s0;
+        s0 = __builtin_rotateleft32(s0, 26) ^ t ^ (t << 9);
+        s1 = __builtin_rotateleft32(t, 13);
+        return (float)(r >> 8) * 5.9604644775390625e-08f;  // 2^-24: rand's Standard f32, [0,1)
+    }
+};
+
+// ---- table access policies ------------------------------------------------------
+struct TblLds {
+    const float4 *p;  // points into __shared__
+    __device__ __forceinline__ float4 ld(uint32_t i) const { return p[i]; }
+};
+struct TblGlobal {
+    const float4 *__restrict__ p;
+    __device__ __forceinline__ float4 ld(uint32_t i) const { return p[i]; }
+};
+
+// ---- intersection ---------------------------------------------------------------
+struct RayK {  // per-ray invariants of the sphere quadratic (sphere.rs:27,33)
+    F3 ro, rd;
+    float a, inv_a;
+};
+__device__ __forceinline__ RayK make_ray(F3 ro, F3 rd) {
+    float a = dot(rd, rd);
+    return RayK{ro, rd, a, rcp(a)};
+}
+
+// sphere.rs:26-34 in half-b form: b = 2h, disc = 4(h^2 - a c), t = (-h - sqrt(h^2 - a c))/a
+// (exactly the same quantities: scaling by 2 and 4 is exact in binary fp).
+__device__ __forceinline__ float sphere_t(const RayK &r, float4 c_r2) {
+    F3 oc = r.ro - f3(c_r2);
+    float h = dot(oc, r.rd);
+    float c = dot(oc, oc) - c_r2.w;
+    float disc = h * h - r.a * c;
+    float t = (-h - fsqrt(disc)) * r.inv_a;
+    // disc < 0 -> sqrt = NaN -> t NaN -> every later comparison is false (miss)
+    return t;
+}
+
+// plane.rs:25-52. Returns t or NaN/-1 on miss. q0={p,uu} q1={n,vv} q2={u,vx} q3={vy,vz,..}
+__device__ __forceinline__ float plane_t(const RayK &r, float4 q0, float4 q1, float4 q2, float4 q3) {
+    F3 n = f3(q1);
+    float denom = dot(n, r.rd);
+    float t = dot(f3(q0) - r.ro, n) * rcp(denom);
+    F3 d = madd(r.ro, r.rd, t) - f3(q0);
+    float du = dot(d, f3(q2));
+    float dv = dot(d, F3{q2.w, q3.x, q3.y});
+    bool ok = (fabsf(denom) >= 1e-6f) && (t > 1e-4f) && (fabsf(du) <= q0.w) && (fabsf(dv) <= q1.w);
+    return ok ? t : -1.0f;
+}
+
+struct HitRec {
+    float t;
+    int idx;  // object index in scene order, -1 = miss
+};
+
+// renderer.rs:356-362: first minimum in scene order.
+template <class Tbl>
+__device__ __forceinline__ HitRec closest_hit(const Tbl &tbl, uint32_t n_obj, const RayK &r) {
+    HitRec best{__builtin_inff(), -1};
+    for (uint32_t i = 0; i < n_obj; ++i) {
+        float4 q3 = tbl.ld(i * OBJ_F4 + 3);
+        float4 q0 = tbl.ld(i * OBJ_F4 + 0);
+        float t;
+        // the object index is wave-uniform, so its kind is: scalar branch
+        if (__builtin_amdgcn_readfirstlane(__float_as_uint(q3.w)) == 0u) {
+            t = sphere_t(r, q0);
+        } else {
+            float4 q1 = tbl.ld(i * OBJ_F4 + 1);
+            float4 q2 = tbl.ld(i * OBJ_F4 + 2);
+            t = plane_t(r, q0, q1, q2, q3);
+        }
+        if (t > 0.0f && t < best.t) {
+            best.t = t;
+            best.idx = (int)i;
+        }
+    }
+    return best;
+}
+
+// Normal + material id of the winning object (sphere.rs:36-37, plane.rs:32).
+template <class Tbl>
+__device__ __forceinline__ void finish_hit(const Tbl &tbl, const RayK &r, HitRec h, F3 &hit, F3 &n, uint32_t &mat) {
+    float4 q0 = tbl.ld(h.idx * OBJ_F4 + 0);
+    float4 q1 = tbl.ld(h.idx * OBJ_F4 + 1);
+    float4 q3 = tbl.ld(h.idx * OBJ_F4 + 3);
+    hit = madd(r.ro, r.rd, h.t);
+    mat = __float_as_uint(q3.z);
+    if (__float_as_uint(q3.w) == 0u) {
+        n = (hit - f3(q0)) * q1.x;
+    } else {
+        F3 pn = f3(q1);
+        n = dot(pn, r.rd) < 0.0f ? pn : -pn;
+    }
+}
+
+// renderer.rs:46: any object with t*t < dist2*0.999, scene order, per-lane early out.
+template <class Tbl, bool COUNT>
+__device__ __forceinline__ bool occluded(const Tbl &tbl, uint32_t n_obj, const RayK &r, float dist2,
+                                         uint32_t &n_sph_tests, uint32_t &n_pl_tests) {
+    float lim = dist2 * 0.999f;
+    bool occ = false;
+    for (uint32_t i = 0; i < n_obj && !occ; ++i) {
+        float4 q3 = tbl.ld(i * OBJ_F4 + 3);
+        float4 q0 = tbl.ld(i * OBJ_F4 + 0);
+        float t;
+        if (__builtin_amdgcn_readfirstlane(__float_as_uint(q3.w)) == 0u) {
+            t = sphere_t(r, q0);
+            if (COUNT) n_sph_tests++;
+        } else {
+            float4 q1 = tbl.ld(i * OBJ_F4 + 1);
+            float4 q2 = tbl.ld(i * OBJ_F4 + 2);
+            t = plane_t(r, q0, q1, q2, q3);
+            if (COUNT) n_pl_tests++;
+        }
+        occ = (t > 0.0f) & (t * t < lim);
+    }
+    return occ;
+}
+
+// ---- BSDF -------------------------------------------------------------------------
+// ggx.rs:5
+__device__ __forceinline__ F3 reflect(F3 v, F3 n) { return madd(v, n, -2.0f * dot(v, n)); }
+// ggx.rs:7-9
+__device__ __forceinline__ F3 fresnel_schlick(float cos_theta, F3 f0) {
+    float w = pow5(1.0f - cos_theta);
+    return F3{fmaf(1.0f - f0.x, w, f0.x), fmaf(1.0f - f0.y, w, f0.y), fmaf(1.0f - f0.z, w, f0.z)};
+}
+// ggx.rs:10-12 (a = roughness, un-squared: quirk Q7)
+__device__ __forceinline__ float d_term(float nh, float a) {
+    float a2 = a * a;
+    float q = fmaf(nh * nh, a2 - 1.0f, 1.0f);
+    return a2 * rcp(3.14159265358979323846f * (q * q));
+}
+// ggx.rs:13-18
+__device__ __forceinline__ float g_term(float nv, float nl, float a) {
+    float k = a * a * 0.5f;
+    float g1 = nv * rcp(fmaf(nv, 1.0f - k, k));
+    float g2 = nl * rcp(fmaf(nl, 1.0f - k, k));
+    return g1 * g2;
+}
+// ggx.rs:20-45 with explicit uniforms
+__device__ __forceinline__ F3 sample_ggx_h(F3 n, float roughness, float r1, float r2) {
+    float a = roughness * roughness;
+    float a2 = a * a;
+    float cos_theta = fsqrt((1.0f - r2) * rcp(fmaf(a2 - 1.0f, r2, 1.0f)));
+    float sin_theta = fsqrt(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+    float hx = cos2pi(r1) * sin_theta, hy = sin2pi(r1) * sin_theta;
+    F3 u = normalize(any_orthonormal(n));
+    F3 v = cross(n, u);
+    return u * hx + v * hy + n * cos_theta;
+}
+// renderer.rs:330-335
+__device__ __forceinline__ F3 diffuse_dir(F3 n, float u_phi, float r2) {
+    F3 u = normalize(any_orthonormal(n));
+    F3 v = cross(n, u);
+    float sr = fsqrt(r2);
+    return normalize(u * (cos2pi(u_phi) * sr) + v * (sin2pi(u_phi) * sr) + n * fsqrt(1.0f - r2));
+}
+// renderer.rs:364-369
+__device__ __forceinline__ bool refract(F3 v, F3 n, float eta_ratio, F3 &out) {
+    float cos_theta = fminf(dot(-v, n), 1.0f);
+    F3 perp = madd(v, n, cos_theta) * eta_ratio;
+    float pp = dot(perp, perp);
+    out = madd(perp, n, -fsqrt(fabsf(1.0f - pp)));
+    return pp < 1.0f;
+}
+// renderer.rs:309-317. rd = incoming direction.
+__device__ __forceinline__ F3 glass_dir(F3 rd, F3 n, float ior, float u) {
+    float cosi = rclamp(-dot(rd, n), -1.0f, 1.0f);
+    bool enter = cosi > 0.0f;
+    float etai = enter ? 1.0f : ior, etat = enter ? ior : 1.0f;
+    F3 hn = enter ? n : -n;
+    float q = (etai - etat) * rcp(etai + etat);
+    float r0 = q * q;
+    float reflectance = fmaf(1.0f - r0, pow5(1.0f - fabsf(cosi)), r0);
+    F3 refl = reflect(rd, hn);
+    F3 refr;
+    bool ok = refract(rd, hn, etai * rcp(etat), refr);
+    return (u < reflectance || !ok) ? refl : refr;
+}
+// renderer.rs:194-202
+__device__ __forceinline__ float sample_phase_function(float g, float r) {
+    if (fabsf(g) < 1e-3f) return 1.0f - 2.0f * r;
+    float g2 = g * g;
+    float term = (1.0f - g2) * rcp(1.0f - g + 2.0f * g * r);
+    return (1.0f + g2 - term * term) * rcp(2.0f * g);
+}
+// renderer.rs:276-282
+__device__ __forceinline__ F3 scatter_dir(F3 rd, float cos_theta, float u_phi) {
+    F3 u = normalize(any_orthonormal(rd));
+    F3 v = cross(rd, u);
+    float sin_theta = fsqrt(1.0f - cos_theta * cos_theta);
+    return normalize(u * (cos2pi(u_phi) * sin_theta) + v * (sin2pi(u_phi) * sin_theta) + rd * cos_theta);
+}
+
+struct Mat {  // material.rs:4-11 after the clamps of renderer.rs:297-298
+    F3 color;
+    float metallic, roughness, ior, density, aniso;
+};
+template <class Tbl>
+__device__ __forceinline__ Mat load_mat(const Tbl &tbl, uint32_t mat_off, uint32_t id) {
+    float4 m0 = tbl.ld(mat_off + id * MAT_F4);
+    float4 m1 = tbl.ld(mat_off + id * MAT_F4 + 1);
+    Mat m;
+    m.color = f3(m0);
+    m.metallic = rclamp(m0.w, 0.0f, 1.0f);
+    m.roughness = rclamp(m1.x, 0.01f, 1.0f);
+    m.ior = m1.y;
+    m.density = m1.z;
+    m.aniso = m1.w;
+    return m;
+}
+
+struct ShadeK {  // per-vertex invariants of renderer.rs:59,63,72
+    F3 n, v, f0, diffuse_over_pi;
+    float n_dot_v, roughness;
+};
+__device__ __forceinline__ ShadeK make_shade(F3 n, F3 v, const Mat &m) {
+    ShadeK s;
+    s.n = n;
+    s.v = v;
+    float om = 1.0f - m.metallic;
+    s.f0 = F3{fmaf(m.color.x, m.metallic, 0.04f * om), fmaf(m.color.y, m.metallic, 0.04f * om),
+              fmaf(m.color.z, m.metallic, 0.04f * om)};
+    s.diffuse_over_pi = m.color * (om * 0.31830988618379067154f);
+    s.n_dot_v = fmaxf(dot(n, v), 1e-4f);
+    s.roughness = m.roughness;
+    return s;
+}
+
+// renderer.rs:49-77: one visible light sample. Returns the contribution
+// (already multiplied by intensity * area * falloff); `lit` tells whether the
+// BRDF branch (:55) was reached.
+__device__ __forceinline__ F3 nee_eval(const ShadeK &s, F3 l, float dist2, F3 light_n, float light_area,
+                                       F3 intensity, bool &lit) {
+    float n_dot_l = fmaxf(dot(s.n, l), 0.0f);
+    float cos_l = fmaxf(-dot(l, light_n), 0.0f);
+    lit = (n_dot_l > 0.0f) & (cos_l > 0.0f);
+    if (!lit) return F3{0.0f, 0.0f, 0.0f};
+    float falloff = cos_l * rcp(dist2);
+    F3 h = normalize(s.v + l);
+    float n_dot_h = fmaxf(dot(s.n, h), 0.0f);
+    float v_dot_h = fmaxf(dot(s.v, h), 0.0f);
+    F3 f = fresnel_schlick(v_dot_h, s.f0);
+    float d = d_term(n_dot_h, s.roughness);
+    float g = g_term(s.n_dot_v, n_dot_l, s.roughness);
+    float spec = d * g * rcp(fmaf(4.0f * s.n_dot_v, n_dot_l, 1e-6f));
+    F3 kd = F3{1.0f - f.x, 1.0f - f.y, 1.0f - f.z};
+    F3 brdf = s.diffuse_over_pi * kd + f * spec;
+    float w = n_dot_l * (light_area * falloff);
+    return brdf * intensity * w;
+}
+
+// renderer.rs:170-178 + algebra.rs:67-73
+__device__ __forceinline__ void camera_ray(const Params &P, uint32_t x, uint32_t y, float jx, float jy, float ds,
+                                           float dt, F3 &ro, F3 &rd) {
+    F3 right = F3{P.cam_right[0], P.cam_right[1], P.cam_right[2]};
+    F3 up = F3{P.cam_up[0], P.cam_up[1], P.cam_up[2]};
+    F3 fwd = F3{P.cam_fwd[0], P.cam_fwd[1], P.cam_fwd[2]};
+    F3 pos = F3{P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]};
+    float u = (((float)x + jx) * P.inv_w - 0.5f) * 2.0f * P.aspect * P.scale;
+    float v = -(((float)y + jy) * P.inv_h - 0.5f) * 2.0f * P.scale;
+    F3 rd0 = normalize(right * u + up * v + fwd);
+    float rad = P.aperture * fsqrt(dt);
+    float dx = rad * cos2pi(ds), dy = rad * sin2pi(ds);
+    F3 focal = madd(pos, rd0, P.focus);
+    ro = pos + right * dx + up * dy;
+    rd = normalize(focal - ro);
+}
+
+// tonemap.rs:10-19
+__device__ __forceinline__ float aces1(float x) {
+    const float a = 2.51f, b = 0.03f, c2 = 2.43f, d = 0.59f, e = 0.14f;
+    return rclamp((x * (a * x + b)) / (x * (c2 * x + d) + e), 0.0f, 1.0f);
+}
+// renderer.rs:187-191 — correctly rounded division and libm powf here: the
+// resolve runs once per pixel and its result is truncated to u8.
+__device__ __forceinline__ uint8_t quantise(float tm) {
+    float q = fminf(powf(tm, 1.0f / 2.2f) * 255.0f, 255.0f);
+    if (!(q > 0.0f)) return 0;
+    if (q >= 255.0f) return 255;
+    return (uint8_t)q;
+}
+
+}  // namespace pt

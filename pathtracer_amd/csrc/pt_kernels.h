@@ -1,0 +1,36 @@
+// pt_kernels.h — host-callable launchers of the kernels in pt_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hippt.h"
+#include "pt_device.h"
+
+namespace pt {
+
+hipError_t launch_megakernel(const Params &P, const float4 *blob, float *accum, unsigned long long *counters,
+                             bool count, bool lds, hipStream_t st);
+hipError_t launch_resolve(const float *accum, uint32_t n_pixels, uint32_t spp, uint8_t *rgba, hipStream_t st);
+
+hipError_t launch_unit_intersect(const Params &P, const float4 *blob, uint32_t n, const float *ro, const float *rd,
+                                 float *t, float *nn, int32_t *idx, hipStream_t st);
+hipError_t launch_unit_occluded(const Params &P, const float4 *blob, uint32_t n, const float *ro, const float *rd,
+                                const float *dist2, uint8_t *out, hipStream_t st);
+hipError_t launch_unit_nee_eval(uint32_t n, const float *nrm, const float *v, const float *l, const float *dist2,
+                                const float *mat, const hippt_light &light, float *out, hipStream_t st);
+hipError_t launch_unit_ggx_terms(uint32_t n, const float *nh, const float *nv, const float *nl, const float *vh,
+                                 const float *rough, const float *f0, float *out5, hipStream_t st);
+hipError_t launch_unit_ggx_sample(uint32_t n, const float *nrm, const float *rough, const float *r1, const float *r2,
+                                  float *out, hipStream_t st);
+hipError_t launch_unit_diffuse(uint32_t n, const float *nrm, const float *u_phi, const float *r2, float *out,
+                               hipStream_t st);
+hipError_t launch_unit_glass(uint32_t n, const float *rd, const float *nrm, const float *ior, const float *u,
+                             float *out, hipStream_t st);
+hipError_t launch_unit_hg(uint32_t n, const float *rd, const float *g, const float *u_hg, const float *u_phi,
+                          float *out4, hipStream_t st);
+hipError_t launch_unit_camera(const Params &P, uint32_t n, const uint32_t *xy, const float *u4, float *out_ro,
+                              float *out_rd, hipStream_t st);
+hipError_t launch_unit_tonemap(uint32_t n3, const float *rgb, uint8_t *out, hipStream_t st);
+hipError_t launch_unit_rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float *out, hipStream_t st);
+
+}  // namespace pt

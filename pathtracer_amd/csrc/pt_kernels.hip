@@ -1,0 +1,469 @@
+// pt_kernels.hip — gfx950 kernels of the path-trace hot path.
+//
+//   pt_megakernel  : renderer.rs:163-182 (sample loop) + :237-353 (trace) for
+//                    every pixel; one lane = one pixel, paths regenerated in
+//                    place so lanes never idle waiting for the wave's longest
+//                    path; object / material / light tables staged in LDS.
+//   pt_resolve     : renderer.rs:184-191 (average, ACES, gamma, u8).
+//   pt_unit_*      : thin kernels around the same device functions, for the
+//                    1e-5 unit-parity tests.
+#include "pt_device.h"
+#include "pt_kernels.h"
+
+namespace pt {
+
+// Lane -> pixel: a 256-thread block covers a 16x16 pixel tile, each wave an
+// 8x8 sub-tile (neighbouring pixels hit the same objects -> coherent branches).
+__device__ __forceinline__ void lane_pixel(const Params &P, uint32_t &x, uint32_t &y) {
+    uint32_t tile = blockIdx.x;
+    uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    x = tx * 16u + (wave & 1u) * 8u + (lane & 7u);
+    y = ty * 16u + (wave >> 1) * 8u + (lane >> 3);
+}
+
+template <class Tbl, bool COUNT>
+struct Tracer {
+    const Params &P;
+    Tbl tbl;
+    uint32_t cnt[HIPPT_N_COUNTERS];
+
+    __device__ __forceinline__ Tracer(const Params &p, Tbl t) : P(p), tbl(t) {
+        if (COUNT)
+            for (int i = 0; i < HIPPT_N_COUNTERS; ++i) cnt[i] = 0;
+    }
+    __device__ __forceinline__ void bump(int k, uint32_t v = 1) {
+        if (COUNT) cnt[k] += v;
+    }
+
+    // renderer.rs:19-85. All lights, 4 shadow samples each, uniforms drawn
+    // before the visibility test (quirk Q10).
+    __device__ __forceinline__ F3 direct_light(F3 x, const ShadeK &sk, Rng &rng) {
+        F3 total = F3{0.0f, 0.0f, 0.0f};
+        bump(HIPPT_C_NEE_VERTICES);
+        for (uint32_t li = 0; li < P.n_light; ++li) {
+            uint32_t o = P.light_off + li * LIGHT_F4;
+            float4 l0 = tbl.ld(o), l1 = tbl.ld(o + 1), l2 = tbl.ld(o + 2), l3 = tbl.ld(o + 3), l4 = tbl.ld(o + 4);
+            F3 contrib = F3{0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+            for (int s = 0; s < 4; ++s) {
+                float e1 = rng.gen() - 0.5f;
+                float e2 = rng.gen() - 0.5f;
+                F3 lp = f3(l0) + f3(l1) * e1 + f3(l2) * e2;
+                F3 lvec = lp - x;
+                float dist2 = dot(lvec, lvec);
+                F3 l = lvec * rsq(dist2);
+                RayK sr = make_ray(madd(x, l, 1e-4f), l);
+                bump(HIPPT_C_SHADOW_RAYS);
+                bool occ = occluded<Tbl, COUNT>(tbl, P.n_obj, sr, dist2, cnt[HIPPT_C_SHADOW_SPHERE_TESTS],
+                                                cnt[HIPPT_C_SHADOW_PLANE_TESTS]);
+                if (!occ) {
+                    bool lit;
+                    F3 c = nee_eval(sk, l, dist2, f3(l4), l0.w, f3(l3), lit);
+                    if (lit) bump(HIPPT_C_LIT_EVALS);
+                    contrib = contrib + c;
+                }
+            }
+            total = madd(total, contrib, 0.25f);  // :82
+        }
+        return total;
+    }
+};
+
+template <class Tbl, bool COUNT>
+__device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x, uint32_t y, bool in_image,
+                                            float *__restrict__ accum, unsigned long long *__restrict__ counters) {
+    Tracer<Tbl, COUNT> tr(P, tbl);
+    const uint32_t pixel = y * P.width + x;
+    const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
+    const uint32_t pix_mixed = mix32(pixel + seed_mixed);
+
+    uint32_t s = P.sample_begin;
+    const uint32_t s_end = in_image ? P.sample_begin + P.sample_count : P.sample_begin;
+
+    F3 sum = F3{0.0f, 0.0f, 0.0f};
+    // path state
+    Rng rng{0u, 1u};
+    F3 ro = F3{0, 0, 0}, rd = F3{0, 0, 1}, T = F3{1, 1, 1}, L = F3{0, 0, 0};
+    uint32_t depth = 0;
+    int media = -1;  // material id of the current medium, -1 = none
+    bool alive = false;
+
+    for (;;) {
+        if (!alive) {
+            if (s >= s_end) break;
+            // renderer.rs:170-178: new camera path
+            rng.seed(seed_mixed, pix_mixed, s);
+            float jx = rng.gen(), jy = rng.gen(), ds = rng.gen(), dt = rng.gen();
+            camera_ray(P, x, y, jx, jy, ds, dt, ro, rd);
+            T = F3{1, 1, 1};
+            L = F3{0, 0, 0};
+            depth = 0;
+            media = -1;
+            alive = true;
+            ++s;
+            tr.bump(HIPPT_C_PATHS);
+        }
+
+        // ---- one vertex of renderer.rs:237-353 ----
+        RayK ray = make_ray(ro, rd);
+        HitRec h = closest_hit(tbl, P.n_obj, ray);
+        tr.bump(HIPPT_C_EXTEND_RAYS);
+        if (h.idx >= 0) tr.bump(HIPPT_C_EXTEND_HITS);
+
+        bool done = false;  // path ends after this vertex
+        F3 A = F3{1, 1, 1};
+        float t_media = __builtin_inff();
+        Mat mm;
+        if (media >= 0) {  // only media with density > 0 are ever entered (:301)
+            mm = load_mat(tbl, P.mat_off, (uint32_t)media);
+            tr.bump(HIPPT_C_MEDIUM_VERTICES);
+            t_media = -fln(rng.gen()) * rcp(mm.density);  // :257
+            float d = fminf(t_media, h.t);
+            float k = -mm.density * d;
+            A = F3{fexp(fmaxf(1.0f - mm.color.x, 0.0f) * k), fexp(fmaxf(1.0f - mm.color.y, 0.0f) * k),
+                   fexp(fmaxf(1.0f - mm.color.z, 0.0f) * k)};  // :261-262
+        }
+
+        if (t_media < h.t) {  // :269 scatter inside the medium
+            tr.bump(HIPPT_C_SCATTER_EVENTS);
+            F3 xs = madd(ro, rd, t_media);
+            ShadeK sk = make_shade(F3{0.0f, 1.0f, 0.0f}, -rd, mm);  // :273 (fixed "up" normal, quirk Q11)
+            F3 D = tr.direct_light(xs, sk, rng);
+            float ct = sample_phase_function(mm.aniso, rng.gen());
+            float up = rng.gen();
+            F3 nd = scatter_dir(rd, ct, up);
+            T = T * A;
+            L = L + T * D;
+            ro = xs;  // no epsilon (:285)
+            rd = nd;
+        } else if (h.idx < 0) {  // :291 sky is black
+            done = true;
+        } else {
+            F3 hit, n;
+            uint32_t mid;
+            finish_hit(tbl, ray, h, hit, n, mid);
+            Mat m = load_mat(tbl, P.mat_off, mid);
+            F3 v = -rd;
+            int next_media = media;  // :301-305
+            if (m.density > 0.0f) next_media = (dot(v, n) > 0.0f) ? (int)mid : -1;
+            T = T * A;
+            if (m.ior > 1.0f && m.metallic < 0.1f) {  // :307 glass
+                tr.bump(HIPPT_C_GLASS_VERTICES);
+                F3 nd = glass_dir(rd, n, m.ior, rng.gen());
+                ro = madd(hit, nd, 1e-4f);
+                rd = nd;
+                media = next_media;
+            } else {  // :323 opaque
+                ShadeK sk = make_shade(n, v, m);
+                F3 D = tr.direct_light(hit, sk, rng);
+                L = L + T * D;
+                float p = fmaxf(fmaxf(m.color.x, m.color.y), m.color.z);  // :327
+                bool cont = depth < 2u;
+                if (!cont) cont = rng.gen() < p;  // drawn only when depth >= 2 (:328)
+                if (cont) {
+                    F3 nd, f;
+                    if (rng.gen() < (1.0f - m.metallic)) {  // :329
+                        tr.bump(HIPPT_C_DIFFUSE_LOBES);
+                        float up = rng.gen(), r2 = rng.gen();
+                        nd = diffuse_dir(n, up, r2);
+                        f = m.color * 0.31830988618379067154f;
+                    } else {
+                        tr.bump(HIPPT_C_SPEC_LOBES);
+                        float r1 = rng.gen(), r2 = rng.gen();
+                        nd = reflect(rd, sample_ggx_h(n, m.roughness, r1, r2));
+                        f = F3{1.0f, 1.0f, 1.0f};
+                    }
+                    float c = dot(nd, n);
+                    if (c > 0.0f) {  // :343
+                        float w = depth >= 2u ? c * rcp(p) : c;
+                        T = T * f * w;
+                        ro = madd(hit, nd, 1e-4f);
+                        rd = nd;
+                        media = next_media;
+                    } else {
+                        done = true;
+                    }
+                } else {
+                    done = true;
+                }
+            }
+        }
+        ++depth;
+        if (done || depth >= P.max_depth) {  // :246
+            sum = sum + L;                   // :181
+            alive = false;
+        }
+    }
+
+    if (in_image) {
+        float *px = accum + (size_t)pixel * 3;
+        px[0] += sum.x;
+        px[1] += sum.y;
+        px[2] += sum.z;
+    }
+    if (COUNT) {
+        // wave-reduce then one atomic per wave and counter
+        for (int k = 0; k < HIPPT_N_COUNTERS; ++k) {
+            uint32_t v = tr.cnt[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&counters[k], (unsigned long long)v);
+        }
+    }
+}
+
+// Scene tables in LDS (north-star layout).
+template <bool COUNT>
+__global__ __launch_bounds__(256) void pt_megakernel_lds(Params P, const float4 *__restrict__ blob,
+                                                         float *__restrict__ accum,
+                                                         unsigned long long *__restrict__ counters) {
+    extern __shared__ float4 s_tbl[];
+    for (uint32_t i = threadIdx.x; i < P.blob_f4; i += 256u) s_tbl[i] = blob[i];
+    __syncthreads();
+    uint32_t x, y;
+    lane_pixel(P, x, y);
+    bool in_image = (x < P.width) & (y < P.height);
+    trace_pixel<TblLds, COUNT>(P, TblLds{s_tbl}, x, y, in_image, accum, counters);
+}
+
+// Scene tables read from global memory (scenes too large for LDS).
+template <bool COUNT>
+__global__ __launch_bounds__(256) void pt_megakernel_global(Params P, const float4 *__restrict__ blob,
+                                                            float *__restrict__ accum,
+                                                            unsigned long long *__restrict__ counters) {
+    uint32_t x, y;
+    lane_pixel(P, x, y);
+    bool in_image = (x < P.width) & (y < P.height);
+    trace_pixel<TblGlobal, COUNT>(P, TblGlobal{blob}, x, y, in_image, accum, counters);
+}
+
+// renderer.rs:184-191
+__global__ __launch_bounds__(256) void pt_resolve(const float *__restrict__ accum, uint32_t n_pixels, float inv_spp,
+                                                  uint8_t *__restrict__ rgba) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_pixels) return;
+    uchar4 o;
+    o.x = quantise(aces1(accum[3 * i + 0] * inv_spp));
+    o.y = quantise(aces1(accum[3 * i + 1] * inv_spp));
+    o.z = quantise(aces1(accum[3 * i + 2] * inv_spp));
+    o.w = 255;
+    reinterpret_cast<uchar4 *>(rgba)[i] = o;
+}
+
+// ---- unit kernels ---------------------------------------------------------------
+__device__ __forceinline__ F3 ld3(const float *p, uint32_t i) { return F3{p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+__device__ __forceinline__ void st3(float *p, uint32_t i, F3 v) {
+    p[3 * i] = v.x;
+    p[3 * i + 1] = v.y;
+    p[3 * i + 2] = v.z;
+}
+
+__global__ void pt_unit_intersect(Params P, const float4 *__restrict__ blob, uint32_t n, const float *ro,
+                                  const float *rd, float *out_t, float *out_n, int32_t *out_idx) {
+    extern __shared__ float4 s_tbl[];
+    for (uint32_t i = threadIdx.x; i < P.blob_f4; i += blockDim.x) s_tbl[i] = blob[i];
+    __syncthreads();
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool act = i < n;
+    uint32_t j = act ? i : 0;
+    TblLds tbl{s_tbl};
+    RayK r = make_ray(ld3(ro, j), ld3(rd, j));
+    HitRec h = closest_hit(tbl, P.n_obj, r);
+    F3 hit, nn = F3{0, 0, 0};
+    uint32_t mid;
+    if (h.idx >= 0) finish_hit(tbl, r, h, hit, nn, mid);
+    if (act) {
+        out_t[i] = h.t;
+        st3(out_n, i, nn);
+        out_idx[i] = h.idx;
+    }
+}
+
+__global__ void pt_unit_occluded(Params P, const float4 *__restrict__ blob, uint32_t n, const float *ro,
+                                 const float *rd, const float *dist2, uint8_t *out) {
+    extern __shared__ float4 s_tbl[];
+    for (uint32_t i = threadIdx.x; i < P.blob_f4; i += blockDim.x) s_tbl[i] = blob[i];
+    __syncthreads();
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    TblLds tbl{s_tbl};
+    RayK r = make_ray(ld3(ro, i), ld3(rd, i));
+    uint32_t a = 0, b = 0;
+    out[i] = occluded<TblLds, false>(tbl, P.n_obj, r, dist2[i], a, b) ? 1 : 0;
+}
+
+__global__ void pt_unit_nee_eval(uint32_t n, const float *nrm, const float *v, const float *l, const float *dist2,
+                                 const float *mat, hippt_light light, float *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Mat m;
+    m.color = F3{mat[8 * i], mat[8 * i + 1], mat[8 * i + 2]};
+    m.metallic = mat[8 * i + 3];
+    m.roughness = mat[8 * i + 4];
+    m.ior = mat[8 * i + 5];
+    m.density = mat[8 * i + 6];
+    m.aniso = mat[8 * i + 7];
+    ShadeK sk = make_shade(ld3(nrm, i), ld3(v, i), m);
+    F3 lu = F3{light.u[0], light.u[1], light.u[2]}, lv = F3{light.v[0], light.v[1], light.v[2]};
+    F3 cr = cross(lu, lv);
+    float area = fsqrt(dot(cr, cr));
+    F3 ln = normalize(cr);
+    bool lit;
+    F3 c = nee_eval(sk, ld3(l, i), dist2[i], ln, area, F3{light.intensity[0], light.intensity[1], light.intensity[2]},
+                    lit);
+    st3(out, i, c);
+}
+
+__global__ void pt_unit_ggx_terms(uint32_t n, const float *nh, const float *nv, const float *nl, const float *vh,
+                                  const float *rough, const float *f0, float *out5) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 f = fresnel_schlick(vh[i], ld3(f0, i));
+    out5[5 * i] = f.x;
+    out5[5 * i + 1] = f.y;
+    out5[5 * i + 2] = f.z;
+    out5[5 * i + 3] = d_term(nh[i], rough[i]);
+    out5[5 * i + 4] = g_term(nv[i], nl[i], rough[i]);
+}
+
+__global__ void pt_unit_ggx_sample(uint32_t n, const float *nrm, const float *rough, const float *r1,
+                                   const float *r2, float *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st3(out, i, sample_ggx_h(ld3(nrm, i), rough[i], r1[i], r2[i]));
+}
+
+__global__ void pt_unit_diffuse(uint32_t n, const float *nrm, const float *u_phi, const float *r2, float *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st3(out, i, diffuse_dir(ld3(nrm, i), u_phi[i], r2[i]));
+}
+
+__global__ void pt_unit_glass(uint32_t n, const float *rd, const float *nrm, const float *ior, const float *u,
+                              float *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st3(out, i, glass_dir(ld3(rd, i), ld3(nrm, i), ior[i], u[i]));
+}
+
+__global__ void pt_unit_hg(uint32_t n, const float *rd, const float *g, const float *u_hg, const float *u_phi,
+                           float *out4) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float c = sample_phase_function(g[i], u_hg[i]);
+    F3 d = scatter_dir(ld3(rd, i), c, u_phi[i]);
+    out4[4 * i] = c;
+    out4[4 * i + 1] = d.x;
+    out4[4 * i + 2] = d.y;
+    out4[4 * i + 3] = d.z;
+}
+
+__global__ void pt_unit_camera(Params P, uint32_t n, const uint32_t *xy, const float *u4, float *out_ro,
+                               float *out_rd) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 ro, rd;
+    camera_ray(P, xy[2 * i], xy[2 * i + 1], u4[4 * i], u4[4 * i + 1], u4[4 * i + 2], u4[4 * i + 3], ro, rd);
+    st3(out_ro, i, ro);
+    st3(out_rd, i, rd);
+}
+
+__global__ void pt_unit_tonemap(uint32_t n3, const float *rgb, uint8_t *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n3) return;
+    out[i] = quantise(aces1(rgb[i]));
+}
+
+__global__ void pt_unit_rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float *out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t sm = mix32(seed ^ 0x85ebca6bu);
+    Rng r;
+    r.seed(sm, mix32(pixel + sm), sample);
+    for (uint32_t i = 0; i < n; ++i) out[i] = r.gen();
+}
+
+// ---- launchers (host) -------------------------------------------------------------
+static inline unsigned grid_for(uint32_t n, unsigned bs = 256) { return (n + bs - 1) / bs; }
+
+hipError_t launch_megakernel(const Params &P, const float4 *blob, float *accum, unsigned long long *counters,
+                             bool count, bool lds, hipStream_t st) {
+    uint32_t tiles_y = (P.height + 15u) / 16u;
+    dim3 grid(P.tiles_x * tiles_y), block(256);
+    size_t shmem = (size_t)P.blob_f4 * sizeof(float4);
+    if (lds) {
+        if (count)
+            hipLaunchKernelGGL(pt_megakernel_lds<true>, grid, block, shmem, st, P, blob, accum, counters);
+        else
+            hipLaunchKernelGGL(pt_megakernel_lds<false>, grid, block, shmem, st, P, blob, accum, counters);
+    } else {
+        if (count)
+            hipLaunchKernelGGL(pt_megakernel_global<true>, grid, block, 0, st, P, blob, accum, counters);
+        else
+            hipLaunchKernelGGL(pt_megakernel_global<false>, grid, block, 0, st, P, blob, accum, counters);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const float *accum, uint32_t n_pixels, uint32_t spp, uint8_t *rgba, hipStream_t st) {
+    hipLaunchKernelGGL(pt_resolve, dim3(grid_for(n_pixels)), dim3(256), 0, st, accum, n_pixels, 1.0f / (float)spp,
+                       rgba);
+    return hipGetLastError();
+}
+
+hipError_t launch_unit_intersect(const Params &P, const float4 *blob, uint32_t n, const float *ro, const float *rd,
+                                 float *t, float *nn, int32_t *idx, hipStream_t st) {
+    hipLaunchKernelGGL(pt_unit_intersect, dim3(grid_for(n)), dim3(256), (size_t)P.blob_f4 * 16, st, P, blob, n, ro, rd,
+                       t, nn, idx);
+    return hipGetLastError();
+}
+hipError_t launch_unit_occluded(const Params &P, const float4 *blob, uint32_t n, const float *ro, const float *rd,
+                                const float *dist2, uint8_t *out, hipStream_t st) {
+    hipLaunchKernelGGL(pt_unit_occluded, dim3(grid_for(n)), dim3(256), (size_t)P.blob_f4 * 16, st, P, blob, n, ro, rd,
+                       dist2, out);
+    return hipGetLastError();
+}
+hipError_t launch_unit_nee_eval(uint32_t n, const float *nrm, const float *v, const float *l, const float *dist2,
+                                const float *mat, const hippt_light &light, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(pt_unit_nee_eval, dim3(grid_for(n)), dim3(256), 0, st, n, nrm, v, l, dist2, mat, light, out);
+    return hipGetLastError();
+}
+hipError_t launch_unit_ggx_terms(uint32_t n, const float *nh, const float *nv, const float *nl, const float *vh,
+                                 const float *rough, const float *f0, float *out5, hipStream_t st) {
+    hipLaunchKernelGGL(pt_unit_ggx_terms, dim3(grid_for(n)), dim3(256), 0, st, n, nh, nv, nl, vh, rough, f0, out5);
+    return hipGetLastError();
+}
+hipError_t launch_unit_ggx_sample(uint32_t n, const float *nrm, const float *rough, const float *r1, const float *r2,
+                                  float *out, hipStream_t st) {
+    hipLaunchKernelGGL(pt_unit_ggx_sample, dim3(grid_for(n)), dim3(256), 0, st, n, nrm, rough, r1, r2, out);
+    return hipGetLastError();
+}
+hipError_t launch_unit_diffuse(uint32_t n, const float *nrm, const float *u_phi, const float *r2, float *out,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(pt_unit_diffuse, dim3(grid_for(n)), dim3(256), 0, st, n, nrm, u_phi, r2, out);
+    return hipGetLastError();
+}
+hipError_t launch_unit_glass(uint32_t n, const float *rd, const float *nrm, const float *ior, const float *u,
+                             float *out, hipStream_t st) {
+    hipLaunchKernelGGL(pt_unit_glass, dim3(grid_for(n)), dim3(256), 0, st, n, rd, nrm, ior, u, out);
+    return hipGetLastError();
+}
+hipError_t launch_unit_hg(uint32_t n, const float *rd, const float *g, const float *u_hg, const float *u_phi,
+                          float *out4, hipStream_t st) {
+    hipLaunchKernelGGL(pt_unit_hg, dim3(grid_for(n)), dim3(256), 0, st, n, rd, g, u_hg, u_phi, out4);
+    return hipGetLastError();
+}
+hipError_t launch_unit_camera(const Params &P, uint32_t n, const uint32_t *xy, const float *u4, float *out_ro,
+                              float *out_rd, hipStream_t st) {
+    hipLaunchKernelGGL(pt_unit_camera, dim3(grid_for(n)), dim3(256), 0, st, P, n, xy, u4, out_ro, out_rd);
+    return hipGetLastError();
+}
+hipError_t launch_unit_tonemap(uint32_t n3, const float *rgb, uint8_t *out, hipStream_t st) {
+    hipLaunchKernelGGL(pt_unit_tonemap, dim3(grid_for(n3)), dim3(256), 0, st, n3, rgb, out);
+    return hipGetLastError();
+}
+hipError_t launch_unit_rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(pt_unit_rng, dim3(1), dim3(64), 0, st, seed, pixel, sample, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace pt
