@@ -1,0 +1,169 @@
+"""C-ABI surface and host-side plumbing (no GPU compute): exports, scene.json loader
+(src/scene.rs), file name (renderer.rs:156-161), PNG writer, error behaviour."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXAMPLE = os.path.join(ROOT, "scenes", "scene.example.json")
+
+
+def _has_gpu():
+    return os.path.exists("/dev/kfd")
+
+
+def test_library_exports_every_declared_symbol():
+    from pathtracer_amd import _abi
+    lib = _abi.load_library()
+    header = open(os.path.join(ROOT, "include", "hippt.h")).read()
+    declared = set(re.findall(r"\b(hippt_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 30
+    for sym in declared:
+        assert hasattr(lib, sym), f"libhippt.so lacks {sym}"
+    assert declared == set(_abi.EXPORTED_SYMBOLS)
+
+
+def test_struct_layouts_match_header():
+    from pathtracer_amd import _abi
+    assert C.sizeof(_abi.Material) == 32 and C.sizeof(_abi.Sphere) == 28 and C.sizeof(_abi.Plane) == 60
+    assert C.sizeof(_abi.Light) == 48 and C.sizeof(_abi.Camera) == 64 and C.sizeof(_abi.Options) == 24
+    assert C.sizeof(_abi.SceneC) == 64 + 8 * 4 + 4 * 8
+
+
+def test_example_scene_loads():
+    from pathtracer_amd import Scene
+    s = Scene.load(EXAMPLE)
+    assert (s.width, s.height, s.samples) == (800, 600, 256)
+    assert len(s.spheres) == 3 and len(s.planes) == 4 and len(s.lights) == 2
+    assert len(s.materials) == 5 + 1                       # + magenta default (scene.rs:112-120)
+    assert list(s.planes["order"]) == [0, 4, 5, 6] and list(s.spheres["order"]) == [1, 2, 3]
+    assert s.camera.focus == 5.0 and np.isclose(s.camera.aperture, 0.02)
+    assert np.isclose(s.camera.aspect, 800 / 600) and np.isclose(s.camera.scale, np.tan(np.radians(30)), rtol=1e-6)
+    j = json.load(open(EXAMPLE))
+    glass = j["materials"]["Glass.006"]
+    sph2 = s.spheres[2]
+    m = s.materials[sph2["material"]]
+    assert np.isclose(m["ior"], glass["ior"]) and np.allclose(m["rgb"], glass["rgb"])
+    # plane normal = normalize(u x v), scene.rs:139
+    p = s.planes[3]
+    n = np.cross(p["u"].astype(np.float64), p["v"].astype(np.float64))
+    assert np.allclose(p["normal"], n / np.linalg.norm(n), atol=1e-6)
+
+
+MINI = {
+    "camera": {"pos": [0, 0, 0], "look_at": [0, 0, 1], "up": [0, 1, 0], "fov": 60, "aperture": 0.0},
+    "render": {"width": 16, "height": 8, "samples": 2},
+    "materials": {"a": {"rgb": [0.1, 0.2, 0.3], "metallic": 0.5, "roughness": 0.25, "ior": 1.0}},
+    "objects": [
+        {"sphere": {"name": "s", "center": [0, 0, 5], "radius": 1, "mat": "a", "in_focus": True}},
+        {"plane": {"name": "p", "point": [0, -1, 0], "u": [1, 0, 0], "v": [0, 0, 1], "mat": "nope", "junk": 7}},
+    ],
+    "lights": [{"pos": [0, 5, 0], "u": [1, 0, 0], "v": [0, 0, 1], "intensity": [1, 2, 3]}],
+    "ignored_top_level_key": [1, 2, {"x": None}],
+}
+
+
+def test_loader_defaults_and_untagged_objects(oracle):
+    from pathtracer_amd import Scene
+    s = Scene.parse(json.dumps(MINI))
+    assert s.materials[0]["volume_density"] == 0 and s.materials[0]["volume_anisotropy"] == 0   # serde default
+    magenta = s.materials[s.planes[0]["material"]]                                              # unknown name
+    assert list(magenta["rgb"]) == [1, 0, 1] and magenta["roughness"] == 1 and magenta["ior"] == 1
+    assert s.spheres[0]["in_focus"] == 1 and s.planes[0]["in_focus"] == 0
+    # autofocus over the in_focus sphere (5x5 probes around the centre of a 16x8 image): host == oracle, bit for bit
+    assert 4.0 < s.camera.focus < 4.5 and s.camera.focus == np.float32(oracle.autofocus(s))
+    assert list(s.planes[0]["normal"]) == [0, -1, 0]
+    s2 = Scene.parse(json.dumps(MINI), width=32, height=32, samples=9)
+    assert (s2.width, s2.height, s2.samples) == (32, 32, 9) and s2.camera.aspect == 1.0
+
+
+@pytest.mark.parametrize("mutate,needle", [
+    (lambda d: d.pop("lights"), "lights"),
+    (lambda d: d["camera"].pop("fov"), "fov"),
+    (lambda d: d["render"].__setitem__("width", -3), "width"),
+    (lambda d: d["render"].__setitem__("samples", 1.5), "samples"),
+    (lambda d: d["materials"]["a"].pop("ior"), "ior"),
+    (lambda d: d["objects"].append({"cube": {}}), "untagged"),
+    (lambda d: d["objects"][0]["sphere"].pop("name"), "name"),
+    (lambda d: d["lights"][0].__setitem__("pos", [1, 2]), "pos"),
+])
+def test_loader_rejects_bad_scenes(mutate, needle):
+    """serde would fail `expect("json parse")` (scene.rs:96); here: HIPPT_ERR_IO with a message."""
+    import copy
+    from pathtracer_amd import HipptError, Scene
+    d = copy.deepcopy(MINI)
+    mutate(d)
+    with pytest.raises(HipptError) as e:
+        Scene.parse(json.dumps(d))
+    assert "json parse" in str(e.value) and needle in str(e.value)
+
+
+def test_loader_rejects_malformed_json_and_missing_file():
+    from pathtracer_amd import HipptError, Scene
+    for bad in ("{", '{"camera": }', "[1,2", '{"a": 1} x', ""):
+        with pytest.raises(HipptError):
+            Scene.parse(bad)
+    with pytest.raises(HipptError) as e:
+        Scene.load("/nonexistent/scene.json")
+    assert "scene file" in str(e.value)                     # scene.rs:95 expect("scene file")
+
+
+def test_json_string_escapes_and_numbers():
+    from pathtracer_amd import Scene
+    d = json.loads(json.dumps(MINI))
+    d["materials"] = {"métal \"x\"\\": {"rgb": [1e-1, 2.5E-1, 0.5], "metallic": 1, "roughness": 1e0, "ior": 1}}
+    d["objects"][0]["sphere"]["mat"] = "métal \"x\"\\"
+    for ensure_ascii in (True, False):
+        s = Scene.parse(json.dumps(d, ensure_ascii=ensure_ascii))
+        assert s.spheres[0]["material"] == 0 and np.allclose(s.materials[0]["rgb"], [0.1, 0.25, 0.5])
+
+
+def test_render_image_name_pattern():
+    from pathtracer_amd import hip_renderer
+    a = hip_renderer.render_image_name(1920, 1080, 1024, 0.02, 5.0)
+    b = hip_renderer.render_image_name(1920, 1080, 1024, 0.02, 5.0)
+    assert re.fullmatch(r"renders/render_1920x1080_s1024_ap0\.02_f5\.0_[A-Za-z0-9]{6}\.png", a), a
+    assert a != b
+
+
+def test_png_writer_roundtrip(tmp_path):
+    from PIL import Image
+    from pathtracer_amd import hip_renderer
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    path = tmp_path / "x.png"
+    hip_renderer.save_png(path, img)
+    back = np.asarray(Image.open(path))
+    assert back.shape == (37, 53, 4) and np.array_equal(back, img)
+
+
+def test_invalid_tables_are_rejected_before_any_launch():
+    from pathtracer_amd import HipptError, Scene, hip_renderer
+    s = Scene.parse(json.dumps(MINI))
+    s.spheres["material"][0] = 99
+    with pytest.raises(HipptError):
+        hip_renderer.render_accum(s)
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly_without_fallback():
+    """No CPU fallback in the product path: without a HIP device every render entry point errors."""
+    from pathtracer_amd import HipptError, Scene, hip_renderer
+    s = Scene.parse(json.dumps(MINI))
+    with pytest.raises(HipptError):
+        hip_renderer.render(s)
+    with pytest.raises(HipptError):
+        hip_renderer.unit_ops().rng(0, 0, 0, 4)
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "pathtracer_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "liboracle" not in txt and "pt_oracle" not in txt and "oracle_lib" not in txt, f
