@@ -86,6 +86,8 @@ int pack_scene(const hippt_scene *sc, PackedScene &out) {
     P.inv_w = 1.0f / (float)sc->width;
     P.inv_h = 1.0f / (float)sc->height;
     P.n_obj = n_obj;
+    P.n_sph = sc->n_spheres;
+    P.n_pl = sc->n_planes;
     P.n_mat = sc->n_materials;
     P.n_light = sc->n_lights;
     P.mat_off = n_obj * pt::OBJ_F4;

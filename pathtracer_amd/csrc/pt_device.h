@@ -33,6 +33,7 @@ struct Params {
     uint32_t width, height;
     float inv_w, inv_h;
     uint32_t n_obj, n_mat, n_light;
+    uint32_t n_sph, n_pl;         // object counts by kind (event counters)
     uint32_t mat_off, light_off;  // float4 offsets into the blob
     uint32_t blob_f4;             // blob size in float4
     uint32_t sample_begin, sample_count, max_depth, seed;

@@ -109,6 +109,8 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
         RayK ray = make_ray(ro, rd);
         HitRec h = closest_hit(tbl, P.n_obj, ray);
         tr.bump(HIPPT_C_EXTEND_RAYS);
+        tr.bump(HIPPT_C_EXTEND_SPHERE_TESTS, P.n_sph);
+        tr.bump(HIPPT_C_EXTEND_PLANE_TESTS, P.n_pl);
         if (h.idx >= 0) tr.bump(HIPPT_C_EXTEND_HITS);
 
         bool done = false;  // path ends after this vertex
