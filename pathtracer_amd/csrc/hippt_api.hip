@@ -7,6 +7,7 @@
 // device and fails with HIPPT_ERR_DEVICE otherwise.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -85,41 +86,48 @@ int pack_scene(const hippt_scene *sc, PackedScene &out) {
     P.height = sc->height;
     P.inv_w = 1.0f / (float)sc->width;
     P.inv_h = 1.0f / (float)sc->height;
-    P.n_obj = n_obj;
     P.n_sph = sc->n_spheres;
     P.n_pl = sc->n_planes;
     P.n_mat = sc->n_materials;
     P.n_light = sc->n_lights;
-    P.mat_off = n_obj * pt::OBJ_F4;
+    P.sph_off = 0;
+    P.pl_off = P.sph_off + P.n_sph;
+    P.aux_off = P.pl_off + P.n_pl * 3u;
+    P.mat_off = P.aux_off + P.n_sph + P.n_pl;
     P.light_off = P.mat_off + sc->n_materials * pt::MAT_F4;
     P.blob_f4 = P.light_off + sc->n_lights * pt::LIGHT_F4;
     P.tiles_x = (sc->width + 15u) / 16u;
     out.blob.assign(P.blob_f4 ? P.blob_f4 : 1, mk4(0, 0, 0, 0));
 
+    // Each table is written in ascending scene order, so that strict '<' inside a table keeps
+    // the first minimum (renderer.rs:359-361).
     std::vector<char> seen(n_obj, 0);
-    for (uint32_t i = 0; i < sc->n_spheres; ++i) {
-        const hippt_sphere &s = sc->spheres[i];
-        if (s.order >= n_obj || seen[s.order]) return hippt_set_error(HIPPT_ERR_INVALID, "sphere %u: bad order %u", i, s.order);
-        if (s.material >= sc->n_materials) return hippt_set_error(HIPPT_ERR_INVALID, "sphere %u: bad material %u", i, s.material);
+    std::vector<uint32_t> si(sc->n_spheres), pi(sc->n_planes);
+    for (uint32_t i = 0; i < sc->n_spheres; ++i) si[i] = i;
+    for (uint32_t i = 0; i < sc->n_planes; ++i) pi[i] = i;
+    std::sort(si.begin(), si.end(), [&](uint32_t a, uint32_t b) { return sc->spheres[a].order < sc->spheres[b].order; });
+    std::sort(pi.begin(), pi.end(), [&](uint32_t a, uint32_t b) { return sc->planes[a].order < sc->planes[b].order; });
+    for (uint32_t k = 0; k < sc->n_spheres; ++k) {
+        const hippt_sphere &s = sc->spheres[si[k]];
+        if (s.order >= n_obj || seen[s.order]) return hippt_set_error(HIPPT_ERR_INVALID, "sphere %u: bad order %u", si[k], s.order);
+        if (s.material >= sc->n_materials) return hippt_set_error(HIPPT_ERR_INVALID, "sphere %u: bad material %u", si[k], s.material);
         seen[s.order] = 1;
-        float4 *q = &out.blob[(size_t)s.order * pt::OBJ_F4];
-        q[0] = mk4(s.center[0], s.center[1], s.center[2], s.radius * s.radius);
-        q[1] = mk4(1.0f / s.radius, s.radius, 0, 0);
-        q[2] = mk4(0, 0, 0, 0);
-        q[3] = mk4(0, 0, as_f(s.material), as_f(0u));
+        out.blob[P.sph_off + k] = mk4(s.center[0], s.center[1], s.center[2], s.radius * s.radius);  // sphere.rs:29
+        out.blob[P.aux_off + k] = mk4(1.0f / s.radius, as_f(s.material), as_f(s.order), 0);        // sphere.rs:37
     }
-    for (uint32_t i = 0; i < sc->n_planes; ++i) {
-        const hippt_plane &p = sc->planes[i];
-        if (p.order >= n_obj || seen[p.order]) return hippt_set_error(HIPPT_ERR_INVALID, "plane %u: bad order %u", i, p.order);
-        if (p.material >= sc->n_materials) return hippt_set_error(HIPPT_ERR_INVALID, "plane %u: bad material %u", i, p.material);
+    for (uint32_t k = 0; k < sc->n_planes; ++k) {
+        const hippt_plane &p = sc->planes[pi[k]];
+        if (p.order >= n_obj || seen[p.order]) return hippt_set_error(HIPPT_ERR_INVALID, "plane %u: bad order %u", pi[k], p.order);
+        if (p.material >= sc->n_materials) return hippt_set_error(HIPPT_ERR_INVALID, "plane %u: bad material %u", pi[k], p.material);
         seen[p.order] = 1;
         float uu = p.u[0] * p.u[0] + p.u[1] * p.u[1] + p.u[2] * p.u[2];  // plane.rs:45
         float vv = p.v[0] * p.v[0] + p.v[1] * p.v[1] + p.v[2] * p.v[2];  // plane.rs:50
-        float4 *q = &out.blob[(size_t)p.order * pt::OBJ_F4];
-        q[0] = mk4(p.point[0], p.point[1], p.point[2], uu);
-        q[1] = mk4(p.normal[0], p.normal[1], p.normal[2], vv);
-        q[2] = mk4(p.u[0], p.u[1], p.u[2], p.v[0]);
-        q[3] = mk4(p.v[1], p.v[2], as_f(p.material), as_f(1u));
+        float iu = 1.0f / uu, iv = 1.0f / vv;  // |d.u| <= u.u  <=>  |d.(u/u.u)| <= 1
+        float4 *q = &out.blob[P.pl_off + (size_t)k * 3];
+        q[0] = mk4(p.point[0], p.point[1], p.point[2], p.normal[0]);
+        q[1] = mk4(p.normal[1], p.normal[2], p.u[0] * iu, p.u[1] * iu);
+        q[2] = mk4(p.u[2] * iu, p.v[0] * iv, p.v[1] * iv, p.v[2] * iv);
+        out.blob[P.aux_off + P.n_sph + k] = mk4(0, as_f(p.material), as_f(p.order), 0);
     }
     for (uint32_t i = 0; i < sc->n_materials; ++i) {
         const hippt_material &m = sc->materials[i];

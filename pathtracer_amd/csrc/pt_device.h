@@ -15,12 +15,11 @@
 namespace pt {
 
 // ---- scene blob layout (float4 units), built by hippt_api.hip ---------------
-//   objects : n_obj  x 4   in scene order (tie rule of renderer.rs:359-361)
-//     sphere : {cx,cy,cz,r*r} {1/r, r, 0, 0} {0,0,0,0}    {0, 0, mat, kind=0}
-//     plane  : {px,py,pz,u.u} {nx,ny,nz,v.v} {ux,uy,uz,vx} {vy,vz, mat, kind=1}
-//   materials : n_mat x 2  {r,g,b,metallic} {roughness,ior,density,anisotropy}
-//   lights    : n_light x 5 {pos,area} {u,0} {v,0} {intensity,0} {normal,0}
-constexpr int OBJ_F4 = 4;
+//   spheres  : n_sph x 1  {cx,cy,cz,r*r}
+//   planes   : n_pl  x 3  {px,py,pz,nx} {ny,nz,u'x,u'y} {u'z,v'x,v'y,v'z}, u' = u/(u.u), v' = v/(v.v)
+//   aux      : (n_sph + n_pl) x 1  {1/r, material, scene order, 0}
+//   materials: n_mat x 2  {r,g,b,metallic} {roughness,ior,density,anisotropy}
+//   lights   : n_light x 5 {pos,area} {u,0} {v,0} {intensity,0} {normal,0}
 constexpr int MAT_F4 = 2;
 constexpr int LIGHT_F4 = 5;
 
@@ -32,9 +31,8 @@ struct Params {
     float aspect, scale, aperture, focus;
     uint32_t width, height;
     float inv_w, inv_h;
-    uint32_t n_obj, n_mat, n_light;
-    uint32_t n_sph, n_pl;         // object counts by kind (event counters)
-    uint32_t mat_off, light_off;  // float4 offsets into the blob
+    uint32_t n_sph, n_pl, n_mat, n_light;
+    uint32_t sph_off, pl_off, aux_off, mat_off, light_off;  // float4 offsets into the blob
     uint32_t blob_f4;             // blob size in float4
     uint32_t sample_begin, sample_count, max_depth, seed;
     uint32_t tiles_x;             // 16x16 pixel tiles per row
@@ -132,94 +130,111 @@ __device__ __forceinline__ RayK make_ray(F3 ro, F3 rd) {
 
 // sphere.rs:26-34 in half-b form: b = 2h, disc = 4(h^2 - a c), t = (-h - sqrt(h^2 - a c))/a
 // (exactly the same quantities: scaling by 2 and 4 is exact in binary fp).
+// disc < 0 -> sqrt = NaN -> t NaN -> every later comparison is false (miss).
 __device__ __forceinline__ float sphere_t(const RayK &r, float4 c_r2) {
     F3 oc = r.ro - f3(c_r2);
     float h = dot(oc, r.rd);
-    float c = dot(oc, oc) - c_r2.w;
+    float c = fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -c_r2.w)));  // oc.oc - r*r
     float disc = h * h - r.a * c;
-    float t = (-h - fsqrt(disc)) * r.inv_a;
-    // disc < 0 -> sqrt = NaN -> t NaN -> every later comparison is false (miss)
-    return t;
+    return (-h - fsqrt(disc)) * r.inv_a;
 }
 
-// plane.rs:25-52. Returns t or NaN/-1 on miss. q0={p,uu} q1={n,vv} q2={u,vx} q3={vy,vz,..}
-__device__ __forceinline__ float plane_t(const RayK &r, float4 q0, float4 q1, float4 q2, float4 q3) {
-    F3 n = f3(q1);
+// plane.rs:25-52, branch-free. q0={p,nx} q1={ny,nz,u'x,u'y} q2={u'z,v'x,v'y,v'z} with
+// u' = u/(u.u), v' = v/(v.v), so the bounds |d.u| <= u.u become |d.u'| <= 1.
+// Returns t, or a value that fails `t > 0` (NaN or -1) on a miss.
+__device__ __forceinline__ float plane_t(const RayK &r, float4 q0, float4 q1, float4 q2) {
+    F3 p = f3(q0);
+    F3 n = F3{q0.w, q1.x, q1.y};
     float denom = dot(n, r.rd);
-    float t = dot(f3(q0) - r.ro, n) * rcp(denom);
-    F3 d = madd(r.ro, r.rd, t) - f3(q0);
-    float du = dot(d, f3(q2));
-    float dv = dot(d, F3{q2.w, q3.x, q3.y});
-    bool ok = (fabsf(denom) >= 1e-6f) && (t > 1e-4f) && (fabsf(du) <= q0.w) && (fabsf(dv) <= q1.w);
+    float t = dot(p - r.ro, n) * rcp(denom);
+    F3 d = madd(r.ro, r.rd, t) - p;
+    float du = dot(d, F3{q1.z, q1.w, q2.x});
+    float dv = dot(d, F3{q2.y, q2.z, q2.w});
+    bool ok = (fabsf(denom) >= 1e-6f) & (t > 1e-4f) & (fmaxf(fabsf(du), fabsf(dv)) <= 1.0f);
     return ok ? t : -1.0f;
 }
 
 struct HitRec {
     float t;
-    int idx;  // object index in scene order, -1 = miss
+    int id;  // index into the aux table (spheres first, then planes), -1 = miss
 };
 
-// renderer.rs:356-362: first minimum in scene order.
+
+// renderer.rs:356-362: closest hit, first minimum in scene order. The object index is
+// wave-uniform, so every table read is a uniform-address read (scalar loads / LDS
+// broadcast) and the loops carry no divergence. Within one table ascending index is
+// ascending scene order, so strict '<' keeps the first minimum; an exact tie between a
+// plane and the current best sphere is resolved by the objects' scene order.
 template <class Tbl>
-__device__ __forceinline__ HitRec closest_hit(const Tbl &tbl, uint32_t n_obj, const RayK &r) {
-    HitRec best{__builtin_inff(), -1};
-    for (uint32_t i = 0; i < n_obj; ++i) {
-        float4 q3 = tbl.ld(i * OBJ_F4 + 3);
-        float4 q0 = tbl.ld(i * OBJ_F4 + 0);
-        float t;
-        // the object index is wave-uniform, so its kind is: scalar branch
-        if (__builtin_amdgcn_readfirstlane(__float_as_uint(q3.w)) == 0u) {
-            t = sphere_t(r, q0);
-        } else {
-            float4 q1 = tbl.ld(i * OBJ_F4 + 1);
-            float4 q2 = tbl.ld(i * OBJ_F4 + 2);
-            t = plane_t(r, q0, q1, q2, q3);
-        }
-        if (t > 0.0f && t < best.t) {
-            best.t = t;
-            best.idx = (int)i;
-        }
+__device__ __forceinline__ HitRec closest_hit(const Tbl &tbl, const Params &P, const RayK &r) {
+    float best_t = __builtin_inff();
+    int best = -1;
+#pragma unroll 4
+    for (uint32_t i = 0; i < P.n_sph; ++i) {
+        float t = sphere_t(r, tbl.ld(P.sph_off + i));
+        bool b = (t > 0.0f) & (t < best_t);
+        best_t = b ? t : best_t;
+        best = b ? (int)i : best;
     }
-    return best;
+#pragma unroll 2
+    for (uint32_t j = 0; j < P.n_pl; ++j) {
+        uint32_t o = P.pl_off + j * 3u;
+        float t = plane_t(r, tbl.ld(o), tbl.ld(o + 1), tbl.ld(o + 2));
+        bool b = (t > 0.0f) & (t < best_t);
+        bool tie = (t == best_t) & (best >= 0) & (best < (int)P.n_sph);
+        if (__builtin_expect(__any(tie), 0)) {  // coincident surfaces only
+            uint32_t ord_p = __float_as_uint(tbl.ld(P.aux_off + P.n_sph + j).z);
+            uint32_t ord_s = tie ? __float_as_uint(tbl.ld(P.aux_off + (uint32_t)best).z) : 0u;
+            b = b | (tie & (ord_p < ord_s));
+        }
+        best_t = b ? t : best_t;
+        best = b ? (int)(P.n_sph + j) : best;
+    }
+    return HitRec{best_t, best};
 }
 
-// Normal + material id of the winning object (sphere.rs:36-37, plane.rs:32).
+// Normal, material id and scene-order index of the winning object (sphere.rs:36-37, plane.rs:32).
 template <class Tbl>
-__device__ __forceinline__ void finish_hit(const Tbl &tbl, const RayK &r, HitRec h, F3 &hit, F3 &n, uint32_t &mat) {
-    float4 q0 = tbl.ld(h.idx * OBJ_F4 + 0);
-    float4 q1 = tbl.ld(h.idx * OBJ_F4 + 1);
-    float4 q3 = tbl.ld(h.idx * OBJ_F4 + 3);
+__device__ __forceinline__ void finish_hit(const Tbl &tbl, const Params &P, const RayK &r, HitRec h, F3 &hit, F3 &n,
+                                           uint32_t &mat, uint32_t &order) {
+    float4 aux = tbl.ld(P.aux_off + (uint32_t)h.id);  // {1/r, mat, order, 0}
     hit = madd(r.ro, r.rd, h.t);
-    mat = __float_as_uint(q3.z);
-    if (__float_as_uint(q3.w) == 0u) {
-        n = (hit - f3(q0)) * q1.x;
+    mat = __float_as_uint(aux.y);
+    order = __float_as_uint(aux.z);
+    if (h.id < (int)P.n_sph) {
+        float4 s = tbl.ld(P.sph_off + (uint32_t)h.id);
+        n = (hit - f3(s)) * aux.x;
     } else {
-        F3 pn = f3(q1);
+        uint32_t o = P.pl_off + ((uint32_t)h.id - P.n_sph) * 3u;
+        float4 q0 = tbl.ld(o), q1 = tbl.ld(o + 1);
+        F3 pn = F3{q0.w, q1.x, q1.y};
         n = dot(pn, r.rd) < 0.0f ? pn : -pn;
     }
 }
 
-// renderer.rs:46: any object with t*t < dist2*0.999, scene order, per-lane early out.
+// renderer.rs:46: any object with t > 0 and t*t < dist2*0.999. Every object is tested,
+// branch-free (on scene.example the reference's first-occluder early out skips only 8 %
+// of the tests, and a per-lane exit costs more in divergence than it saves); the wave
+// skips the plane table when the spheres already occlude all of its lanes.
 template <class Tbl, bool COUNT>
-__device__ __forceinline__ bool occluded(const Tbl &tbl, uint32_t n_obj, const RayK &r, float dist2,
+__device__ __forceinline__ bool occluded(const Tbl &tbl, const Params &P, const RayK &r, float dist2,
                                          uint32_t &n_sph_tests, uint32_t &n_pl_tests) {
     float lim = dist2 * 0.999f;
     bool occ = false;
-    for (uint32_t i = 0; i < n_obj && !occ; ++i) {
-        float4 q3 = tbl.ld(i * OBJ_F4 + 3);
-        float4 q0 = tbl.ld(i * OBJ_F4 + 0);
-        float t;
-        if (__builtin_amdgcn_readfirstlane(__float_as_uint(q3.w)) == 0u) {
-            t = sphere_t(r, q0);
-            if (COUNT) n_sph_tests++;
-        } else {
-            float4 q1 = tbl.ld(i * OBJ_F4 + 1);
-            float4 q2 = tbl.ld(i * OBJ_F4 + 2);
-            t = plane_t(r, q0, q1, q2, q3);
-            if (COUNT) n_pl_tests++;
-        }
-        occ = (t > 0.0f) & (t * t < lim);
+#pragma unroll 4
+    for (uint32_t i = 0; i < P.n_sph; ++i) {
+        float t = sphere_t(r, tbl.ld(P.sph_off + i));
+        occ = occ | ((t > 0.0f) & (t * t < lim));
     }
+    if (COUNT) n_sph_tests += P.n_sph;
+    if (__all(occ)) return true;
+#pragma unroll 2
+    for (uint32_t j = 0; j < P.n_pl; ++j) {
+        uint32_t o = P.pl_off + j * 3u;
+        float t = plane_t(r, tbl.ld(o), tbl.ld(o + 1), tbl.ld(o + 2));
+        occ = occ | ((t > 0.0f) & (t * t < lim));
+    }
+    if (COUNT) n_pl_tests += P.n_pl;
     return occ;
 }
 

@@ -55,7 +55,7 @@ struct Tracer {
                 F3 l = lvec * rsq(dist2);
                 RayK sr = make_ray(madd(x, l, 1e-4f), l);
                 bump(HIPPT_C_SHADOW_RAYS);
-                bool occ = occluded<Tbl, COUNT>(tbl, P.n_obj, sr, dist2, cnt[HIPPT_C_SHADOW_SPHERE_TESTS],
+                bool occ = occluded<Tbl, COUNT>(tbl, P, sr, dist2, cnt[HIPPT_C_SHADOW_SPHERE_TESTS],
                                                 cnt[HIPPT_C_SHADOW_PLANE_TESTS]);
                 if (!occ) {
                     bool lit;
@@ -107,11 +107,11 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
 
         // ---- one vertex of renderer.rs:237-353 ----
         RayK ray = make_ray(ro, rd);
-        HitRec h = closest_hit(tbl, P.n_obj, ray);
+        HitRec h = closest_hit(tbl, P, ray);
         tr.bump(HIPPT_C_EXTEND_RAYS);
         tr.bump(HIPPT_C_EXTEND_SPHERE_TESTS, P.n_sph);
         tr.bump(HIPPT_C_EXTEND_PLANE_TESTS, P.n_pl);
-        if (h.idx >= 0) tr.bump(HIPPT_C_EXTEND_HITS);
+        if (h.id >= 0) tr.bump(HIPPT_C_EXTEND_HITS);
 
         bool done = false;  // path ends after this vertex
         F3 A = F3{1, 1, 1};
@@ -139,12 +139,12 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
             L = L + T * D;
             ro = xs;  // no epsilon (:285)
             rd = nd;
-        } else if (h.idx < 0) {  // :291 sky is black
+        } else if (h.id < 0) {  // :291 sky is black
             done = true;
         } else {
             F3 hit, n;
-            uint32_t mid;
-            finish_hit(tbl, ray, h, hit, n, mid);
+            uint32_t mid, order;
+            finish_hit(tbl, P, ray, h, hit, n, mid, order);
             Mat m = load_mat(tbl, P.mat_off, mid);
             F3 v = -rd;
             int next_media = media;  // :301-305
@@ -270,14 +270,14 @@ __global__ void pt_unit_intersect(Params P, const float4 *__restrict__ blob, uin
     uint32_t j = act ? i : 0;
     TblLds tbl{s_tbl};
     RayK r = make_ray(ld3(ro, j), ld3(rd, j));
-    HitRec h = closest_hit(tbl, P.n_obj, r);
+    HitRec h = closest_hit(tbl, P, r);
     F3 hit, nn = F3{0, 0, 0};
-    uint32_t mid;
-    if (h.idx >= 0) finish_hit(tbl, r, h, hit, nn, mid);
+    uint32_t mid, order = 0;
+    if (h.id >= 0) finish_hit(tbl, P, r, h, hit, nn, mid, order);
     if (act) {
         out_t[i] = h.t;
         st3(out_n, i, nn);
-        out_idx[i] = h.idx;
+        out_idx[i] = h.id >= 0 ? (int32_t)order : -1;
     }
 }
 
@@ -291,7 +291,7 @@ __global__ void pt_unit_occluded(Params P, const float4 *__restrict__ blob, uint
     TblLds tbl{s_tbl};
     RayK r = make_ray(ld3(ro, i), ld3(rd, i));
     uint32_t a = 0, b = 0;
-    out[i] = occluded<TblLds, false>(tbl, P.n_obj, r, dist2[i], a, b) ? 1 : 0;
+    out[i] = occluded<TblLds, false>(tbl, P, r, dist2[i], a, b) ? 1 : 0;
 }
 
 __global__ void pt_unit_nee_eval(uint32_t n, const float *nrm, const float *v, const float *l, const float *dist2,

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _compare(acc_h, acc_o, spp, q50=1e-5, q90=1e-4, q99=1e-2):
+def _compare(acc_h, acc_o, spp, q50=1e-5, q90=1e-4, q99=1e-2, mean_tol=5e-3):
     """Per-pixel |hip - oracle| relative to the pixel's radiance sum: quantile bounds.
 
     scene.example.json has mirror-like metals (roughness 0.01): there D = a2/(pi q^2) with
@@ -24,7 +24,13 @@ def _compare(acc_h, acc_o, spp, q50=1e-5, q90=1e-4, q99=1e-2):
     by ~1e4 on BOTH sides, so highlight pixels agree only to ~1e-3..1e-2; every other pixel
     agrees to rounding unless a branch flipped (grazing hit/miss, u < R, roulette)."""
     mean_h, mean_o = acc_h.mean(axis=(0, 1)) / spp, acc_o.mean(axis=(0, 1)) / spp
-    assert np.all(np.abs(mean_h - mean_o) <= 1e-3 * np.abs(mean_o) + 1e-7), (mean_h, mean_o)
+    # north star: mean radiance within 1 %. Held: 0.5 % on the raw mean — at these small sample counts
+    # > 90 % of the total difference sits in ~10 highlight samples of radiance ~200 whose sign is random
+    # (measured over 8 seeds: -1.3e-3 .. +3.1e-3) — and 1e-4 once the 0.5 % most different pixels are left out.
+    assert np.all(np.abs(mean_h - mean_o) <= mean_tol * np.abs(mean_o) + 1e-7), (mean_h, mean_o)
+    dsum = (acc_h.astype(np.float64) - acc_o).sum(axis=2)
+    keep = np.abs(dsum) <= np.quantile(np.abs(dsum), 0.995)
+    assert abs(dsum[keep].sum()) <= 1e-4 * acc_o.astype(np.float64).sum(axis=2)[keep].sum()
     err = np.abs(acc_h.astype(np.float64) - acc_o).max(axis=2)
     scale = np.maximum(np.abs(acc_o).max(axis=2), 1e-3 * spp)
     r = err / scale
@@ -43,9 +49,13 @@ def test_example_scene_sample_exact(oracle):
     # event counters: same paths, same events up to the few flipped branches
     assert cn_h["paths"] == cn_o["paths"] == 96 * 72 * 64
     for k in ("extend_rays", "extend_hits", "shadow_rays", "nee_vertices", "lit_evals", "diffuse_lobes",
-              "spec_lobes", "glass_vertices", "shadow_sphere_tests", "shadow_plane_tests"):
+              "spec_lobes", "glass_vertices", "extend_sphere_tests", "extend_plane_tests"):
         assert abs(cn_h[k] - cn_o[k]) <= 2e-3 * cn_o[k] + 8, (k, cn_h[k], cn_o[k])
     assert cn_h["medium_vertices"] == 0 and cn_h["scatter_events"] == 0
+    # shadow tests are counted as executed: the oracle leaves at a ray's first occluder, the kernel
+    # only when its whole wave is occluded
+    assert cn_o["shadow_sphere_tests"] <= cn_h["shadow_sphere_tests"] <= 3 * cn_h["shadow_rays"]
+    assert cn_o["shadow_plane_tests"] <= cn_h["shadow_plane_tests"] <= 4 * cn_h["shadow_rays"]
 
 
 def test_matte_scene_tight(oracle):
@@ -56,7 +66,7 @@ def test_matte_scene_tight(oracle):
     s.materials["roughness"] = np.maximum(s.materials["roughness"], 0.5)
     acc_h = hip_renderer.render_accum(s, seed=4)
     acc_o = oracle.render_accum(s, seed=4)
-    _compare(acc_h, acc_o, 32, q50=2e-6, q90=1e-5, q99=1e-3)
+    _compare(acc_h, acc_o, 32, q50=2e-6, q90=1e-5, q99=1e-3, mean_tol=1e-4)
 
 
 def test_tables_global_variant_matches_lds(oracle):
