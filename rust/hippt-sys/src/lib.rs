@@ -1,0 +1,36 @@
+//! Raw bindings to include/hippt.h (the subset the `--gpu` path needs).
+//! UNVERIFIED IN THIS ENVIRONMENT (no Rust toolchain in the build image).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int};
+
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct hippt_material { pub rgb: [f32; 3], pub metallic: f32, pub roughness: f32, pub ior: f32,
+                            pub volume_density: f32, pub volume_anisotropy: f32 }
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct hippt_sphere { pub center: [f32; 3], pub radius: f32, pub material: u32, pub order: u32, pub in_focus: u32 }
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct hippt_plane { pub point: [f32; 3], pub u: [f32; 3], pub v: [f32; 3], pub normal: [f32; 3],
+                         pub material: u32, pub order: u32, pub in_focus: u32 }
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct hippt_light { pub pos: [f32; 3], pub u: [f32; 3], pub v: [f32; 3], pub intensity: [f32; 3] }
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct hippt_camera { pub pos: [f32; 3], pub right: [f32; 3], pub up: [f32; 3], pub forward: [f32; 3],
+                          pub aspect: f32, pub scale: f32, pub aperture: f32, pub focus: f32 }
+#[repr(C)]
+pub struct hippt_scene {
+    pub camera: hippt_camera,
+    pub width: u32, pub height: u32, pub samples: u32,
+    pub n_materials: u32, pub n_spheres: u32, pub n_planes: u32, pub n_lights: u32, pub reserved: u32,
+    pub materials: *const hippt_material, pub spheres: *const hippt_sphere,
+    pub planes: *const hippt_plane, pub lights: *const hippt_light,
+}
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct hippt_options { pub sample_begin: u32, pub sample_count: u32, pub max_depth: u32, pub seed: u32,
+                           pub flags: u32, pub device: i32 }
+
+extern "C" {
+    pub fn hippt_last_error() -> *const c_char;
+    pub fn hippt_render_rgba8(scene: *const hippt_scene, opts: *const hippt_options, out_rgba: *mut u8) -> c_int;
+    pub fn hippt_render_accum_f32(scene: *const hippt_scene, opts: *const hippt_options, out_accum: *mut f32,
+                                  counters: *mut u64) -> c_int;
+}
