@@ -247,7 +247,8 @@ int hippt_test_intersect(const hippt_scene *scene, uint32_t n, const float *ro,
 int hippt_test_intersect_bvh(const hippt_scene *scene, uint32_t n, const float *ro,
                              const float *rd, float *out_t, float *out_normal,
                              int32_t *out_index, int device);
-/* shadow test of src/renderer.rs:46: any hit with t*t < dist2*0.999. */
+/* shadow test of src/renderer.rs:46: any hit with t > 0 and t*t < dist2*0.999, for rays
+ * ro + t*rd with UNIT-length rd (the routine the NEE kernel uses, origin offset folded out). */
 int hippt_test_occluded(const hippt_scene *scene, uint32_t n, const float *ro,
                         const float *rd, const float *dist2, uint8_t *out, int device);
 /* one unoccluded light sample, src/renderer.rs:49-77. mat = n x 8 floats in

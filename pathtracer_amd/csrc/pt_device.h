@@ -212,30 +212,59 @@ __device__ __forceinline__ void finish_hit(const Tbl &tbl, const Params &P, cons
     }
 }
 
-// renderer.rs:46: any object with t > 0 and t*t < dist2*0.999. Every object is tested,
-// branch-free (on scene.example the reference's first-occluder early out skips only 8 %
-// of the tests, and a per-lane exit costs more in divergence than it saves); the wave
-// skips the plane table when the spheres already occlude all of its lanes.
-template <class Tbl, bool COUNT>
-__device__ __forceinline__ bool occluded(const Tbl &tbl, const Params &P, const RayK &r, float dist2,
-                                         uint32_t &n_sph_tests, uint32_t &n_pl_tests) {
-    float lim = dist2 * 0.999f;
-    bool occ = false;
-#pragma unroll 4
+// renderer.rs:44-46 for NS shadow rays that leave the same point x: origin x + l*eps, unit
+// direction l[s], occluded iff some object has t > 0 (plane: t > 1e-4) and t*t < lim[s]
+// (= dist2*0.999). Every object is tested, branch-free (on scene.example the reference's
+// first-occluder early out skips only 8 % of the tests, and a per-lane exit costs more in
+// divergence than it saves). The loops are object-major so that each table row is read once
+// per NS rays and the terms that depend only on (x, object) are formed once:
+//   sphere: oc = X + eps l, X = x - c  =>  h = oc.l = X.l + eps        (l.l = 1 to rounding)
+//           oc.oc - r^2 = K + 2 eps X.l + eps^2, K = X.X - r^2
+//   plane : (p - o).n = Dn - eps n.l, Dn = (p - x).n  =>  t = Dn/(n.l) - eps
+//           hit - p = (x - p) + l (t + eps)            =>  d.u' = Du + (t + eps) l.u'
+// which is the arithmetic of sphere.rs:26-33 / plane.rs:25-52 re-associated (differences
+// ~1e-7 relative in t; they can only move an occlusion decision that sits on its threshold).
+template <class Tbl, int NS, bool COUNT>
+__device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, F3 x, float eps, const F3 (&l)[NS],
+                                               const float (&lim)[NS], bool (&occ)[NS], uint32_t &n_sph_tests,
+                                               uint32_t &n_pl_tests) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) occ[s] = false;
+    const float eps2 = eps * eps, two_eps = 2.0f * eps;
+#pragma unroll 2
     for (uint32_t i = 0; i < P.n_sph; ++i) {
-        float t = sphere_t(r, tbl.ld(P.sph_off + i));
-        occ = occ | ((t > 0.0f) & (t * t < lim));
+        float4 c = tbl.ld(P.sph_off + i);
+        F3 X = x - f3(c);
+        float K = fmaf(X.z, X.z, fmaf(X.y, X.y, fmaf(X.x, X.x, eps2 - c.w)));  // X.X - r^2 + eps^2
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float d1 = dot(X, l[s]);
+            float h = d1 + eps;
+            float cs = fmaf(two_eps, d1, K);
+            float t = -h - fsqrt(fmaf(h, h, -cs));
+            occ[s] = occ[s] | ((t > 0.0f) & (t * t < lim[s]));
+        }
     }
-    if (COUNT) n_sph_tests += P.n_sph;
-    if (__all(occ)) return true;
+    if (COUNT) n_sph_tests += NS * P.n_sph;
 #pragma unroll 2
     for (uint32_t j = 0; j < P.n_pl; ++j) {
         uint32_t o = P.pl_off + j * 3u;
-        float t = plane_t(r, tbl.ld(o), tbl.ld(o + 1), tbl.ld(o + 2));
-        occ = occ | ((t > 0.0f) & (t * t < lim));
+        float4 q0 = tbl.ld(o), q1 = tbl.ld(o + 1), q2 = tbl.ld(o + 2);
+        F3 n = F3{q0.w, q1.x, q1.y}, u = F3{q1.z, q1.w, q2.x}, v = F3{q2.y, q2.z, q2.w};
+        F3 Xp = x - f3(q0);
+        float Dn = -dot(Xp, n), Du = dot(Xp, u), Dv = dot(Xp, v);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float denom = dot(n, l[s]);
+            float tp = Dn * rcp(denom);
+            float t = tp - eps;
+            float du = fmaf(tp, dot(l[s], u), Du);
+            float dv = fmaf(tp, dot(l[s], v), Dv);
+            bool ok = (fabsf(denom) >= 1e-6f) & (t > 1e-4f) & (fmaxf(fabsf(du), fabsf(dv)) <= 1.0f);
+            occ[s] = occ[s] | (ok & (t * t < lim[s]));
+        }
     }
-    if (COUNT) n_pl_tests += P.n_pl;
-    return occ;
+    if (COUNT) n_pl_tests += NS * P.n_pl;
 }
 
 // ---- BSDF -------------------------------------------------------------------------

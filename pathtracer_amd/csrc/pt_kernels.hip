@@ -45,21 +45,28 @@ struct Tracer {
             uint32_t o = P.light_off + li * LIGHT_F4;
             float4 l0 = tbl.ld(o), l1 = tbl.ld(o + 1), l2 = tbl.ld(o + 2), l3 = tbl.ld(o + 3), l4 = tbl.ld(o + 4);
             F3 contrib = F3{0.0f, 0.0f, 0.0f};
-#pragma unroll 1
+            // the light's 4 shadow samples (:35-47) are drawn first, then tested together
+            F3 l[4];
+            float dist2[4], lim[4];
+            bool occ[4];
+#pragma unroll
             for (int s = 0; s < 4; ++s) {
                 float e1 = rng.gen() - 0.5f;
                 float e2 = rng.gen() - 0.5f;
                 F3 lp = f3(l0) + f3(l1) * e1 + f3(l2) * e2;
                 F3 lvec = lp - x;
-                float dist2 = dot(lvec, lvec);
-                F3 l = lvec * rsq(dist2);
-                RayK sr = make_ray(madd(x, l, 1e-4f), l);
-                bump(HIPPT_C_SHADOW_RAYS);
-                bool occ = occluded<Tbl, COUNT>(tbl, P, sr, dist2, cnt[HIPPT_C_SHADOW_SPHERE_TESTS],
-                                                cnt[HIPPT_C_SHADOW_PLANE_TESTS]);
-                if (!occ) {
+                dist2[s] = dot(lvec, lvec);
+                l[s] = lvec * rsq(dist2[s]);
+                lim[s] = dist2[s] * 0.999f;
+            }
+            bump(HIPPT_C_SHADOW_RAYS, 4);
+            occluded_multi<Tbl, 4, COUNT>(tbl, P, x, 1e-4f, l, lim, occ, cnt[HIPPT_C_SHADOW_SPHERE_TESTS],
+                                          cnt[HIPPT_C_SHADOW_PLANE_TESTS]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (!occ[s]) {
                     bool lit;
-                    F3 c = nee_eval(sk, l, dist2, f3(l4), l0.w, f3(l3), lit);
+                    F3 c = nee_eval(sk, l[s], dist2[s], f3(l4), l0.w, f3(l3), lit);
                     if (lit) bump(HIPPT_C_LIT_EVALS);
                     contrib = contrib + c;
                 }
@@ -289,9 +296,13 @@ __global__ void pt_unit_occluded(Params P, const float4 *__restrict__ blob, uint
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     TblLds tbl{s_tbl};
-    RayK r = make_ray(ld3(ro, i), ld3(rd, i));
+    // production shadow routine with the origin offset folded out (eps = 0); rd must be unit length
+    F3 l[1] = {ld3(rd, i)};
+    float lim[1] = {dist2[i] * 0.999f};
+    bool occ[1];
     uint32_t a = 0, b = 0;
-    out[i] = occluded<TblLds, false>(tbl, P, r, dist2[i], a, b) ? 1 : 0;
+    occluded_multi<TblLds, 1, false>(tbl, P, ld3(ro, i), 0.0f, l, lim, occ, a, b);
+    out[i] = occ[0] ? 1 : 0;
 }
 
 __global__ void pt_unit_nee_eval(uint32_t n, const float *nrm, const float *v, const float *l, const float *dist2,
