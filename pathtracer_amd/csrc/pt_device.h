@@ -231,7 +231,7 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
 #pragma unroll
     for (int s = 0; s < NS; ++s) occ[s] = false;
     const float eps2 = eps * eps, two_eps = 2.0f * eps;
-#pragma unroll 2
+#pragma unroll 1
     for (uint32_t i = 0; i < P.n_sph; ++i) {
         float4 c = tbl.ld(P.sph_off + i);
         F3 X = x - f3(c);
@@ -246,7 +246,7 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
         }
     }
     if (COUNT) n_sph_tests += NS * P.n_sph;
-#pragma unroll 2
+#pragma unroll 1
     for (uint32_t j = 0; j < P.n_pl; ++j) {
         uint32_t o = P.pl_off + j * 3u;
         float4 q0 = tbl.ld(o), q1 = tbl.ld(o + 1), q2 = tbl.ld(o + 2);

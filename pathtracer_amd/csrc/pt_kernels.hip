@@ -47,7 +47,7 @@ struct Tracer {
             F3 contrib = F3{0.0f, 0.0f, 0.0f};
             // the light's 4 shadow samples (:35-47) are drawn first, then tested together
             F3 l[4];
-            float dist2[4], lim[4];
+            float lim[4];  // dist2 * 0.999 (:46)
             bool occ[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -55,9 +55,9 @@ struct Tracer {
                 float e2 = rng.gen() - 0.5f;
                 F3 lp = f3(l0) + f3(l1) * e1 + f3(l2) * e2;
                 F3 lvec = lp - x;
-                dist2[s] = dot(lvec, lvec);
-                l[s] = lvec * rsq(dist2[s]);
-                lim[s] = dist2[s] * 0.999f;
+                float dist2 = dot(lvec, lvec);
+                l[s] = lvec * rsq(dist2);
+                lim[s] = dist2 * 0.999f;
             }
             bump(HIPPT_C_SHADOW_RAYS, 4);
             occluded_multi<Tbl, 4, COUNT>(tbl, P, x, 1e-4f, l, lim, occ, cnt[HIPPT_C_SHADOW_SPHERE_TESTS],
@@ -66,7 +66,7 @@ struct Tracer {
             for (int s = 0; s < 4; ++s) {
                 if (!occ[s]) {
                     bool lit;
-                    F3 c = nee_eval(sk, l[s], dist2[s], f3(l4), l0.w, f3(l3), lit);
+                    F3 c = nee_eval(sk, l[s], lim[s] * (1.0f / 0.999f), f3(l4), l0.w, f3(l3), lit);
                     if (lit) bump(HIPPT_C_LIT_EVALS);
                     contrib = contrib + c;
                 }
@@ -91,7 +91,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
     F3 sum = F3{0.0f, 0.0f, 0.0f};
     // path state
     Rng rng{0u, 1u};
-    F3 ro = F3{0, 0, 0}, rd = F3{0, 0, 1}, T = F3{1, 1, 1}, L = F3{0, 0, 0};
+    F3 ro = F3{0, 0, 0}, rd = F3{0, 0, 1}, T = F3{1, 1, 1};
     uint32_t depth = 0;
     int media = -1;  // material id of the current medium, -1 = none
     bool alive = false;
@@ -104,7 +104,6 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
             float jx = rng.gen(), jy = rng.gen(), ds = rng.gen(), dt = rng.gen();
             camera_ray(P, x, y, jx, jy, ds, dt, ro, rd);
             T = F3{1, 1, 1};
-            L = F3{0, 0, 0};
             depth = 0;
             media = -1;
             alive = true;
@@ -143,7 +142,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
             float up = rng.gen();
             F3 nd = scatter_dir(rd, ct, up);
             T = T * A;
-            L = L + T * D;
+            sum = sum + T * D;  // :181 + :285, added straight into the pixel sum
             ro = xs;  // no epsilon (:285)
             rd = nd;
         } else if (h.id < 0) {  // :291 sky is black
@@ -166,7 +165,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
             } else {  // :323 opaque
                 ShadeK sk = make_shade(n, v, m);
                 F3 D = tr.direct_light(hit, sk, rng);
-                L = L + T * D;
+                sum = sum + T * D;
                 float p = fmaxf(fmaxf(m.color.x, m.color.y), m.color.z);  // :327
                 bool cont = depth < 2u;
                 if (!cont) cont = rng.gen() < p;  // drawn only when depth >= 2 (:328)
@@ -199,10 +198,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
             }
         }
         ++depth;
-        if (done || depth >= P.max_depth) {  // :246
-            sum = sum + L;                   // :181
-            alive = false;
-        }
+        if (done || depth >= P.max_depth) alive = false;  // :246
     }
 
     if (in_image) {
@@ -222,8 +218,11 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
 }
 
 // Scene tables in LDS (north-star layout).
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 5  // waves per SIMD the register allocator must allow (launch_bounds 2nd argument)
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(256) void pt_megakernel_lds(Params P, const float4 *__restrict__ blob,
+__global__ __launch_bounds__(256, PT_MIN_WAVES) void pt_megakernel_lds(Params P, const float4 *__restrict__ blob,
                                                          float *__restrict__ accum,
                                                          unsigned long long *__restrict__ counters) {
     extern __shared__ float4 s_tbl[];
