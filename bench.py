@@ -49,7 +49,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step")
-    ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "scene.example.json"))
+    ap.add_argument("--scene", default=None, help="scene.json path (overrides --config's scene)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"],
+                    help="BASELINE config: c2 scene.example (default, the headline), c3 glass+fog, c4 100k spheres + LBVH")
     ap.add_argument("--max-depth", type=int, default=5)
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -70,7 +72,14 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     W, H, SPP = args.width, args.height, args.spp
-    scene = Scene.load(args.scene, W, H, SPP * world)
+    if args.scene:
+        scene, scene_name = Scene.load(args.scene, W, H, SPP * world), os.path.basename(args.scene)
+    elif args.config == "c4":
+        from pathtracer_amd.synthetic import synthetic_spheres
+        scene, scene_name = synthetic_spheres(100000, 0x5EED, W, H, SPP * world), "synthetic_spheres(n=100000, seed=0x5EED), LBVH"
+    else:
+        scene_name = {"c2": "scene.example.json", "c3": "glass_fog.json"}[args.config]
+        scene = Scene.load(os.path.join(ROOT, "scenes", scene_name), W, H, SPP * world)
     ctx = hip_renderer.Context(local_rank)
     ctx.set_scene(scene)
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
@@ -135,7 +144,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C2: scene.example.json {W}x{H}, {SPP} spp per GPU ({SPP * world} spp image), "
+            "config": {"workload": f"{args.config.upper()}: {scene_name} {W}x{H}, {SPP} spp per GPU ({SPP * world} spp image), "
                                    f"max_depth {args.max_depth}, seed 0",
                        "parallelism": f"sample-range split over {world} GPU(s), one RCCL reduce" if world > 1 else "1 GPU",
                        "kernel": "wavefront" if args.flags & _abi.FLAG_WAVEFRONT else "megakernel",

@@ -48,6 +48,8 @@ namespace {
 constexpr uint64_t kPathsPerLaunch = 4ull << 30;
 // LDS budget for the staged tables (default dynamic LDS limit per block).
 constexpr size_t kMaxLdsBlob = 60 * 1024;
+// Sphere count from which hippt_set_scene builds the LBVH (brute force wins below).
+constexpr uint32_t kBvhMinSpheres = 64;
 
 struct PackedScene {
     pt::Params P{};
@@ -113,7 +115,7 @@ int pack_scene(const hippt_scene *sc, PackedScene &out) {
         if (s.material >= sc->n_materials) return hippt_set_error(HIPPT_ERR_INVALID, "sphere %u: bad material %u", si[k], s.material);
         seen[s.order] = 1;
         out.blob[P.sph_off + k] = mk4(s.center[0], s.center[1], s.center[2], s.radius * s.radius);  // sphere.rs:29
-        out.blob[P.aux_off + k] = mk4(1.0f / s.radius, as_f(s.material), as_f(s.order), 0);        // sphere.rs:37
+        out.blob[P.aux_off + k] = mk4(1.0f / s.radius, as_f(s.material), as_f(s.order), s.radius);  // sphere.rs:37
     }
     for (uint32_t k = 0; k < sc->n_planes; ++k) {
         const hippt_plane &p = sc->planes[pi[k]];
@@ -155,6 +157,23 @@ int pack_scene(const hippt_scene *sc, PackedScene &out) {
 
 }  // namespace
 
+namespace {
+int build_bvh(const float4 *d_blob, const pt::Params &P, pt::BvhBuffers &out, hipStream_t st, int *depth) {
+    if (P.n_sph < 2) return hippt_set_error(HIPPT_ERR_INVALID, "LBVH needs at least 2 spheres");
+    hipError_t e = pt::bvh_build(d_blob + P.sph_off, d_blob + P.aux_off, P.n_sph, out, st, depth);
+    if (e != hipSuccess) {
+        pt::bvh_free(out);
+        return hippt_set_error(HIPPT_ERR_DEVICE, "LBVH build failed: %s", hipGetErrorString(e));
+    }
+    if (*depth > pt::BVH_STACK) {
+        pt::bvh_free(out);
+        return hippt_set_error(HIPPT_ERR_LIMIT, "LBVH depth %d exceeds the traversal stack (%d)", *depth, pt::BVH_STACK);
+    }
+    return HIPPT_OK;
+}
+pt::Bvh bvh_view(const pt::BvhBuffers &b) { return pt::Bvh{b.nodes, b.sph_sorted, b.aux_sorted, b.n}; }
+}  // namespace
+
 struct hippt_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -164,6 +183,8 @@ struct hippt_context {
     size_t d_blob_cap = 0;
     unsigned long long *d_counters = nullptr;
     uint32_t samples = 0;
+    pt::BvhBuffers bvh;  // LBVH over the spheres (many-sphere scenes only)
+    int bvh_depth = 0;
     // kernel timing (events on the launch stream)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
@@ -200,6 +221,7 @@ int hippt_destroy(hippt_context *ctx) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
     }
+    pt::bvh_free(ctx->bvh);
     if (ctx->d_blob) (void)hipFree(ctx->d_blob);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -222,7 +244,14 @@ int hippt_set_scene(hippt_context *ctx, const hippt_scene *scene) {
         HIP_TRY(hipMalloc(&ctx->d_blob, bytes));
         ctx->d_blob_cap = bytes;
     }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(ctx->d_blob, ps.blob.data(), bytes, hipMemcpyHostToDevice));
+    pt::bvh_free(ctx->bvh);
+    ctx->bvh_depth = 0;
+    if (scene->n_spheres >= kBvhMinSpheres) {
+        int rc2 = build_bvh(ctx->d_blob, ps.P, ctx->bvh, ctx->stream, &ctx->bvh_depth);
+        if (rc2) return rc2;
+    }
     ctx->scene = std::move(ps);
     ctx->samples = scene->samples;
     ctx->has_scene = true;
@@ -245,6 +274,15 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
     bool count = (o.flags & HIPPT_FLAG_COUNTERS) != 0;
     bool lds = (size_t)P.blob_f4 * sizeof(float4) <= kMaxLdsBlob;
     if (o.flags & HIPPT_FLAG_TABLES_GLOBAL) lds = false;
+    bool use_bvh = ctx->bvh.n > 0 && !(o.flags & HIPPT_FLAG_NO_BVH);
+    if ((o.flags & HIPPT_FLAG_BVH) && !use_bvh) {
+        if (o.flags & HIPPT_FLAG_NO_BVH) return hippt_set_error(HIPPT_ERR_INVALID, "HIPPT_FLAG_BVH and HIPPT_FLAG_NO_BVH are exclusive");
+        if (ctx->bvh.n == 0) {  // forced on a scene below the automatic threshold
+            int rc2 = build_bvh(ctx->d_blob, ctx->scene.P, ctx->bvh, ctx->stream, &ctx->bvh_depth);
+            if (rc2) return rc2;
+        }
+        use_bvh = true;
+    }
     uint64_t pixels = (uint64_t)P.width * P.height;
     uint64_t per = kPathsPerLaunch / pixels;
     if (per < 1) per = 1;
@@ -261,7 +299,10 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
         }
         auto &ev = ctx->ev_pool[ctx->ev_used++];
         HIP_TRY(hipEventRecord(ev.first, st));
-        HIP_TRY(pt::launch_megakernel(P, ctx->d_blob, d_accum, ctx->d_counters, count, lds, st));
+        if (use_bvh)
+            HIP_TRY(pt::launch_megakernel_bvh(P, ctx->d_blob, bvh_view(ctx->bvh), d_accum, ctx->d_counters, count, st));
+        else
+            HIP_TRY(pt::launch_megakernel(P, ctx->d_blob, d_accum, ctx->d_counters, count, lds, st));
         HIP_TRY(hipEventRecord(ev.second, st));
         s0 += c;
         cnt -= c;
@@ -408,7 +449,7 @@ int hippt_test_intersect(const hippt_scene *scene, uint32_t n, const float *ro, 
     PackedScene ps;
     rc = pack_scene(scene, ps);
     if (rc) return rc;
-    if (ps.blob.size() * 16 > kMaxLdsBlob) return hippt_set_error(HIPPT_ERR_LIMIT, "scene tables exceed the LDS budget of the unit kernel");
+    bool lds = ps.blob.size() * 16 <= kMaxLdsBlob;
     DevBuf blob, dro, drd, dt, dn, di;
     UP(blob, ps.blob.data(), ps.blob.size() * 16);
     UP(dro, ro, (size_t)n * 12);
@@ -416,7 +457,8 @@ int hippt_test_intersect(const hippt_scene *scene, uint32_t n, const float *ro, 
     HIP_TRY(dt.alloc((size_t)n * 4));
     HIP_TRY(dn.alloc((size_t)n * 12));
     HIP_TRY(di.alloc((size_t)n * 4));
-    if (n) HIP_TRY(pt::launch_unit_intersect(ps.P, blob.as<float4>(), n, dro.as<float>(), drd.as<float>(), dt.as<float>(), dn.as<float>(), di.as<int32_t>(), nullptr));
+    if (n && lds) HIP_TRY(pt::launch_unit_intersect(ps.P, blob.as<float4>(), n, dro.as<float>(), drd.as<float>(), dt.as<float>(), dn.as<float>(), di.as<int32_t>(), nullptr));
+    if (n && !lds) HIP_TRY(pt::launch_unit_intersect_global(ps.P, blob.as<float4>(), n, dro.as<float>(), drd.as<float>(), dt.as<float>(), dn.as<float>(), di.as<int32_t>(), nullptr));
     DOWN(out_t, dt, (size_t)n * 4);
     DOWN(out_normal, dn, (size_t)n * 12);
     DOWN(out_index, di, (size_t)n * 4);
@@ -574,9 +616,33 @@ int hippt_test_rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t n, f
     return HIPPT_OK;
 }
 
-int hippt_test_intersect_bvh(const hippt_scene *, uint32_t, const float *, const float *, float *, float *, int32_t *,
-                             int) {
-    return hippt_set_error(HIPPT_ERR_INVALID, "LBVH path not built in this version");
+int hippt_test_intersect_bvh(const hippt_scene *scene, uint32_t n, const float *ro, const float *rd, float *out_t,
+                             float *out_normal, int32_t *out_index, int device) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    PackedScene ps;
+    rc = pack_scene(scene, ps);
+    if (rc) return rc;
+    DevBuf blob, dro, drd, dt, dn, di;
+    UP(blob, ps.blob.data(), ps.blob.size() * 16);
+    pt::BvhBuffers bb;
+    int depth = 0;
+    rc = build_bvh(blob.as<float4>(), ps.P, bb, nullptr, &depth);
+    if (rc) return rc;
+    struct Guard {
+        pt::BvhBuffers &b;
+        ~Guard() { pt::bvh_free(b); }
+    } guard{bb};
+    UP(dro, ro, (size_t)n * 12);
+    UP(drd, rd, (size_t)n * 12);
+    HIP_TRY(dt.alloc((size_t)n * 4));
+    HIP_TRY(dn.alloc((size_t)n * 12));
+    HIP_TRY(di.alloc((size_t)n * 4));
+    if (n) HIP_TRY(pt::launch_unit_intersect_bvh(ps.P, blob.as<float4>(), bvh_view(bb), n, dro.as<float>(), drd.as<float>(), dt.as<float>(), dn.as<float>(), di.as<int32_t>(), nullptr));
+    DOWN(out_t, dt, (size_t)n * 4);
+    DOWN(out_normal, dn, (size_t)n * 12);
+    DOWN(out_index, di, (size_t)n * 4);
+    return HIPPT_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,136 @@
+// pt_bvh.h — device-side traversal of the GPU-built LBVH over the sphere table.
+//
+// Used only for many-sphere scenes (BASELINE config C4); the reference has no
+// acceleration structure: its closest hit is the brute-force loop of
+// src/renderer.rs:356-362, and the traversal below must return exactly that
+// loop's answer (same t, same object, first-in-scene-order on ties). It does so
+// by construction: the BVH only prunes — every sphere that can win is tested with
+// the same sphere_t() the brute-force kernels use, boxes are conservative, and the
+// winner is chosen by (t, scene order).
+#pragma once
+#include "pt_device.h"
+
+namespace pt {
+
+// Node = 4 x float4 (64 B, one cache line):
+//   n0 = {Llo.x, Llo.y, Llo.z, Lhi.x}  n1 = {Lhi.y, Lhi.z, Rlo.x, Rlo.y}
+//   n2 = {Rlo.z, Rhi.x, Rhi.y, Rhi.z}  n3 = {left, right, -, -}  (int bits)
+// child >= 0: internal node index; child < 0: leaf ~child = position in the
+// Morton-sorted sphere arrays.
+struct Bvh {
+    const float4 *__restrict__ nodes;
+    const float4 *__restrict__ sph;  // sorted {c, r*r}
+    const float4 *__restrict__ aux;  // sorted {1/r, material, scene order, 0}
+    uint32_t n;                      // number of spheres (>= 2)
+};
+
+constexpr int BVH_STACK = 48;  // entries per lane (LDS); deeper trees raise an error at build time
+
+struct BoxRay {
+    F3 ro, inv;
+};
+__device__ __forceinline__ BoxRay make_box_ray(F3 ro, F3 rd) {
+    auto safe = [](float d) { return fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d; };
+    return BoxRay{ro, F3{rcp(safe(rd.x)), rcp(safe(rd.y)), rcp(safe(rd.z))}};
+}
+// Entry distance of the ray into the box, +inf if it misses or lies beyond t_max / behind the origin.
+__device__ __forceinline__ float box_entry(const BoxRay &b, F3 lo, F3 hi, float t_max) {
+    float x0 = (lo.x - b.ro.x) * b.inv.x, x1 = (hi.x - b.ro.x) * b.inv.x;
+    float y0 = (lo.y - b.ro.y) * b.inv.y, y1 = (hi.y - b.ro.y) * b.inv.y;
+    float z0 = (lo.z - b.ro.z) * b.inv.z, z1 = (hi.z - b.ro.z) * b.inv.z;
+    float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+    float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_max));
+    return tmin <= tmax ? tmin : __builtin_inff();
+}
+
+// Closest sphere hit. best_t/best_leaf/best_ord are updated in place (start: inf, -1, ~0u).
+// stack: this lane's LDS column, element k at stack[k * stride].
+__device__ __forceinline__ void bvh_closest(const Bvh &B, const RayK &r, float &best_t, int &best_leaf,
+                                            uint32_t &best_ord, uint32_t *stack, uint32_t stride, uint32_t &n_tests) {
+    BoxRay br = make_box_ray(r.ro, r.rd);
+    auto leaf = [&](int lf) {
+        float t = sphere_t(r, B.sph[lf]);
+        ++n_tests;
+        if (t > 0.0f && t <= best_t) {
+            uint32_t ord = __float_as_uint(B.aux[lf].z);
+            if (t < best_t || ord < best_ord) {  // renderer.rs:359-361: first minimum in scene order
+                best_t = t;
+                best_leaf = lf;
+                best_ord = ord;
+            }
+        }
+    };
+    int node = 0, sp = 0;
+    for (;;) {
+        float4 n0 = B.nodes[node * 4 + 0], n1 = B.nodes[node * 4 + 1], n2 = B.nodes[node * 4 + 2],
+               n3 = B.nodes[node * 4 + 3];
+        int left = (int)__float_as_uint(n3.x), right = (int)__float_as_uint(n3.y);
+        // boxes are tested against best_t inclusively: a sphere that ties must still be visited
+        float tl = box_entry(br, F3{n0.x, n0.y, n0.z}, F3{n0.w, n1.x, n1.y}, best_t);
+        float tr = box_entry(br, F3{n1.z, n1.w, n2.x}, F3{n2.y, n2.z, n2.w}, best_t);
+        bool hl = tl < __builtin_inff(), hr = tr < __builtin_inff();
+        if (hl && left < 0) {
+            leaf(~left);
+            hl = false;
+        }
+        if (hr && right < 0) {
+            leaf(~right);
+            hr = false;
+        }
+        if (hl && hr) {
+            bool lfirst = tl <= tr;
+            stack[sp * stride] = (uint32_t)(lfirst ? right : left);
+            ++sp;
+            node = lfirst ? left : right;
+        } else if (hl || hr) {
+            node = hl ? left : right;
+        } else {
+            if (sp == 0) break;
+            --sp;
+            node = (int)stack[sp * stride];
+        }
+    }
+}
+
+// Any sphere with t > 0 and t*t < lim (renderer.rs:46).
+__device__ __forceinline__ bool bvh_any(const Bvh &B, const RayK &r, float lim, uint32_t *stack, uint32_t stride,
+                                        uint32_t &n_tests) {
+    BoxRay br = make_box_ray(r.ro, r.rd);
+    float t_max = fsqrt(lim) * 1.000001f;
+    bool occ = false;
+    int node = 0, sp = 0;
+    for (;;) {
+        float4 n0 = B.nodes[node * 4 + 0], n1 = B.nodes[node * 4 + 1], n2 = B.nodes[node * 4 + 2],
+               n3 = B.nodes[node * 4 + 3];
+        int left = (int)__float_as_uint(n3.x), right = (int)__float_as_uint(n3.y);
+        bool hl = box_entry(br, F3{n0.x, n0.y, n0.z}, F3{n0.w, n1.x, n1.y}, t_max) < __builtin_inff();
+        bool hr = box_entry(br, F3{n1.z, n1.w, n2.x}, F3{n2.y, n2.z, n2.w}, t_max) < __builtin_inff();
+        if (hl && left < 0) {
+            float t = sphere_t(r, B.sph[~left]);
+            ++n_tests;
+            occ = occ | ((t > 0.0f) & (t * t < lim));
+            hl = false;
+        }
+        if (hr && right < 0) {
+            float t = sphere_t(r, B.sph[~right]);
+            ++n_tests;
+            occ = occ | ((t > 0.0f) & (t * t < lim));
+            hr = false;
+        }
+        if (occ) break;
+        if (hl && hr) {
+            stack[sp * stride] = (uint32_t)right;
+            ++sp;
+            node = left;
+        } else if (hl || hr) {
+            node = hl ? left : right;
+        } else {
+            if (sp == 0) break;
+            --sp;
+            node = (int)stack[sp * stride];
+        }
+    }
+    return occ;
+}
+
+}  // namespace pt

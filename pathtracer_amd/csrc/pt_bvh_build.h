@@ -1,0 +1,20 @@
+// pt_bvh_build.h — host entry points of the GPU LBVH build (pt_bvh_build.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pt {
+
+struct BvhBuffers {
+    float4 *nodes = nullptr;       // (n-1) x 4 float4
+    float4 *sph_sorted = nullptr;  // n x {c, r*r}, Morton order
+    float4 *aux_sorted = nullptr;  // n x {1/r, material, scene order, r}
+    uint32_t n = 0;
+};
+
+// Builds the LBVH over n >= 2 spheres given as device arrays {c, r*r} and {1/r, material, order, r}.
+// Synchronises `st`. depth_out = height of the tree (bounds the traversal stack).
+hipError_t bvh_build(const float4 *d_sph, const float4 *d_aux, uint32_t n, BvhBuffers &out, hipStream_t st, int *depth_out);
+void bvh_free(BvhBuffers &b);
+
+}  // namespace pt

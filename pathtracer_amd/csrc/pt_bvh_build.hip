@@ -1,0 +1,256 @@
+// pt_bvh_build.hip — GPU construction of the LBVH over the sphere table
+// (north star "Optional BVH"; BASELINE config C4). Not in the reference.
+//
+//   1. bounds of the sphere centres            (block reduce + ordered-int atomics)
+//   2. 30-bit Morton code per centre            (10 bits per axis)
+//   3. stable radix sort of (code, index)       (rocPRIM device radix sort)
+//   4. Karras 2012 binary radix tree over keys (code << 32 | sorted position)
+//   5. leaf boxes, then bottom-up refit, one launch per level (a kernel boundary is the
+//      only inter-workgroup ordering relied upon: no in-launch flags, cf. guide G16)
+//   6. pack 64-byte traversal nodes {left box, right box, children}
+#include <hip/hip_runtime.h>
+
+#include <cstring>  // rocprim's texture iterator needs ::memset on the host side
+#include <rocprim/rocprim.hpp>
+
+#include "pt_bvh_build.h"
+
+namespace pt {
+namespace {
+
+__device__ __forceinline__ uint32_t f2o(float f) {  // order-preserving float -> uint
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float o2f(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+__global__ void k_bounds(const float4 *__restrict__ sph, uint32_t n, uint32_t *bounds /*lo3, hi3*/) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (; i < n; i += gridDim.x * blockDim.x) {
+        float4 s = sph[i];
+        lo[0] = fminf(lo[0], s.x), lo[1] = fminf(lo[1], s.y), lo[2] = fminf(lo[2], s.z);
+        hi[0] = fmaxf(hi[0], s.x), hi[1] = fmaxf(hi[1], s.y), hi[2] = fmaxf(hi[2], s.z);
+    }
+    for (int k = 0; k < 3; ++k) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&bounds[k], f2o(lo[k]));
+            atomicMax(&bounds[3 + k], f2o(hi[k]));
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t expand10(uint32_t v) {  // 10 bits -> every third bit
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__global__ void k_morton(const float4 *__restrict__ sph, uint32_t n, const uint32_t *__restrict__ bounds, uint32_t *codes,
+                         uint32_t *idx) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 s = sph[i];
+    float c[3] = {s.x, s.y, s.z};
+    uint32_t q[3];
+    for (int k = 0; k < 3; ++k) {
+        float lo = o2f(bounds[k]), hi = o2f(bounds[3 + k]);
+        float ext = fmaxf(hi - lo, 1e-30f);
+        float u = fminf(fmaxf((c[k] - lo) / ext * 1024.0f, 0.0f), 1023.0f);
+        q[k] = (uint32_t)u;
+    }
+    codes[i] = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+    idx[i] = i;
+}
+
+// delta(i, j) of Karras 2012 on the unique keys (code << 32 | position); -1 outside [0, n).
+__device__ __forceinline__ int delta(const uint32_t *__restrict__ codes, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    uint64_t a = ((uint64_t)codes[i] << 32) | (uint32_t)i, b = ((uint64_t)codes[j] << 32) | (uint32_t)j;
+    return __clzll((long long)(a ^ b));
+}
+
+// Internal node i in [0, n-2]; leaves are numbered n-1+k in the parent array.
+__global__ void k_hierarchy(const uint32_t *__restrict__ codes, int n, int *left, int *right, int *parent) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = (delta(codes, n, i, i + 1) - delta(codes, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = delta(codes, n, i, i - d);
+    int lmax = 2;
+    while (delta(codes, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(codes, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta(codes, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+        if (delta(codes, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t <= 1) break;
+    }
+    int gamma = i + s * d + min(d, 0);
+    int lo = min(i, j), hi = max(i, j);
+    int lc = (lo == gamma) ? ~gamma : gamma;          // leaf children are stored as ~position
+    int rc = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+    left[i] = lc;
+    right[i] = rc;
+    parent[lc < 0 ? (n - 1 + ~lc) : lc] = i;
+    parent[rc < 0 ? (n - 1 + ~rc) : rc] = i;
+    if (i == 0) parent[0] = -1;
+}
+
+// Conservative sphere box: the traversal must never prune a sphere the brute-force loop would hit.
+__global__ void k_leaf_boxes(const float4 *__restrict__ sph_sorted, const float4 *__restrict__ aux_sorted, int n, float4 *lo,
+                             float4 *hi, int *ready) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    float4 s = sph_sorted[k];
+    float r = aux_sorted[k].w;  // radius
+    float pad = r * 1e-4f + 1e-5f * fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), 1.0f));
+    float e = r + pad;
+    lo[n - 1 + k] = make_float4(s.x - e, s.y - e, s.z - e, 0);
+    hi[n - 1 + k] = make_float4(s.x + e, s.y + e, s.z + e, 0);
+    ready[n - 1 + k] = 1;
+}
+
+// One refit level: an internal node whose children were ready BEFORE this launch gets its box.
+__global__ void k_refit_level(int n, const int *__restrict__ left, const int *__restrict__ right, float4 *lo, float4 *hi,
+                              const int *__restrict__ ready_in, int *ready_out, int *n_done) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    if (ready_in[i]) return;
+    int l = left[i], r = right[i];
+    int li = l < 0 ? n - 1 + ~l : l, ri = r < 0 ? n - 1 + ~r : r;
+    if (!ready_in[li] || !ready_in[ri]) return;
+    float4 a = lo[li], b = lo[ri], c = hi[li], d = hi[ri];
+    lo[i] = make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), 0);
+    hi[i] = make_float4(fmaxf(c.x, d.x), fmaxf(c.y, d.y), fmaxf(c.z, d.z), 0);
+    ready_out[i] = 1;
+    atomicAdd(n_done, 1);
+}
+
+__global__ void k_copy_ready(int n_nodes, const int *__restrict__ src, int *dst) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_nodes) dst[i] = src[i];
+}
+
+__global__ void k_pack(int n, const int *__restrict__ left, const int *__restrict__ right, const float4 *__restrict__ lo,
+                       const float4 *__restrict__ hi, float4 *nodes) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int l = left[i], r = right[i];
+    int li = l < 0 ? n - 1 + ~l : l, ri = r < 0 ? n - 1 + ~r : r;
+    float4 a = lo[li], b = hi[li], c = lo[ri], d = hi[ri];
+    nodes[i * 4 + 0] = make_float4(a.x, a.y, a.z, b.x);
+    nodes[i * 4 + 1] = make_float4(b.y, b.z, c.x, c.y);
+    nodes[i * 4 + 2] = make_float4(c.z, d.x, d.y, d.z);
+    nodes[i * 4 + 3] = make_float4(__uint_as_float((uint32_t)l), __uint_as_float((uint32_t)r), 0, 0);
+}
+
+__global__ void k_gather(const float4 *__restrict__ sph, const float4 *__restrict__ aux, const uint32_t *__restrict__ idx,
+                         uint32_t n, float4 *sph_sorted, float4 *aux_sorted) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t i = idx[k];
+    sph_sorted[k] = sph[i];
+    aux_sorted[k] = aux[i];
+}
+
+struct Tmp {
+    void *p = nullptr;
+    ~Tmp() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+}  // namespace
+
+#define BVH_TRY(expr)                    \
+    do {                                 \
+        hipError_t e_ = (expr);          \
+        if (e_ != hipSuccess) return e_; \
+    } while (0)
+
+hipError_t bvh_build(const float4 *d_sph, const float4 *d_aux, uint32_t n, BvhBuffers &out, hipStream_t st, int *depth_out) {
+    if (n < 2) return hipErrorInvalidValue;
+    const int N = (int)n, n_nodes = 2 * N - 1;
+    Tmp bounds, codes, codes_s, idx, idx_s, sort_tmp, left, right, parent, lo, hi, ready_a, ready_b, done;
+    BVH_TRY(hipMalloc(&bounds.p, 6 * 4));
+    BVH_TRY(hipMalloc(&codes.p, (size_t)n * 4));
+    BVH_TRY(hipMalloc(&codes_s.p, (size_t)n * 4));
+    BVH_TRY(hipMalloc(&idx.p, (size_t)n * 4));
+    BVH_TRY(hipMalloc(&idx_s.p, (size_t)n * 4));
+    BVH_TRY(hipMalloc(&left.p, (size_t)n * 4));
+    BVH_TRY(hipMalloc(&right.p, (size_t)n * 4));
+    BVH_TRY(hipMalloc(&parent.p, (size_t)n_nodes * 4));
+    BVH_TRY(hipMalloc(&lo.p, (size_t)n_nodes * 16));
+    BVH_TRY(hipMalloc(&hi.p, (size_t)n_nodes * 16));
+    BVH_TRY(hipMalloc(&ready_a.p, (size_t)n_nodes * 4));
+    BVH_TRY(hipMalloc(&ready_b.p, (size_t)n_nodes * 4));
+    BVH_TRY(hipMalloc(&done.p, 4));
+    BVH_TRY(hipMalloc((void **)&out.nodes, (size_t)(N - 1) * 64));
+    BVH_TRY(hipMalloc((void **)&out.sph_sorted, (size_t)n * 16));
+    BVH_TRY(hipMalloc((void **)&out.aux_sorted, (size_t)n * 16));
+    out.n = n;
+
+    const unsigned bs = 256, g = (n + bs - 1) / bs, gn = (n_nodes + bs - 1) / bs;
+    uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    BVH_TRY(hipMemcpyAsync(bounds.p, init, sizeof init, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_bounds, dim3(std::min(g, 1024u)), dim3(bs), 0, st, d_sph, n, (uint32_t *)bounds.p);
+    hipLaunchKernelGGL(k_morton, dim3(g), dim3(bs), 0, st, d_sph, n, (const uint32_t *)bounds.p, (uint32_t *)codes.p,
+                       (uint32_t *)idx.p);
+    size_t tmp_bytes = 0;
+    BVH_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint32_t *)codes.p, (uint32_t *)codes_s.p, (uint32_t *)idx.p,
+                                      (uint32_t *)idx_s.p, n, 0, 30, st));
+    BVH_TRY(hipMalloc(&sort_tmp.p, tmp_bytes ? tmp_bytes : 4));
+    BVH_TRY(rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes, (uint32_t *)codes.p, (uint32_t *)codes_s.p, (uint32_t *)idx.p,
+                                      (uint32_t *)idx_s.p, n, 0, 30, st));
+    hipLaunchKernelGGL(k_gather, dim3(g), dim3(bs), 0, st, d_sph, d_aux, (const uint32_t *)idx_s.p, n, out.sph_sorted,
+                       out.aux_sorted);
+    hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(bs), 0, st, (const uint32_t *)codes_s.p, N, (int *)left.p, (int *)right.p,
+                       (int *)parent.p);
+    BVH_TRY(hipMemsetAsync(ready_a.p, 0, (size_t)n_nodes * 4, st));
+    hipLaunchKernelGGL(k_leaf_boxes, dim3(g), dim3(bs), 0, st, out.sph_sorted, out.aux_sorted, N, (float4 *)lo.p, (float4 *)hi.p,
+                       (int *)ready_a.p);
+    // bottom-up, one launch per level; the number of levels is the tree depth
+    int total = 0, depth = 0;
+    for (; total < N - 1; ++depth) {
+        if (depth > 4 * 64) return hipErrorUnknown;  // a level that completes no node: malformed tree
+        hipLaunchKernelGGL(k_copy_ready, dim3(gn), dim3(bs), 0, st, n_nodes, (const int *)ready_a.p, (int *)ready_b.p);
+        BVH_TRY(hipMemsetAsync(done.p, 0, 4, st));
+        hipLaunchKernelGGL(k_refit_level, dim3(g), dim3(bs), 0, st, N, (const int *)left.p, (const int *)right.p, (float4 *)lo.p,
+                           (float4 *)hi.p, (const int *)ready_a.p, (int *)ready_b.p, (int *)done.p);
+        int d = 0;
+        BVH_TRY(hipMemcpyAsync(&d, done.p, 4, hipMemcpyDeviceToHost, st));
+        BVH_TRY(hipStreamSynchronize(st));
+        if (d == 0) return hipErrorUnknown;
+        total += d;
+        std::swap(ready_a.p, ready_b.p);
+    }
+    hipLaunchKernelGGL(k_pack, dim3(g), dim3(bs), 0, st, N, (const int *)left.p, (const int *)right.p, (const float4 *)lo.p,
+                       (const float4 *)hi.p, out.nodes);
+    BVH_TRY(hipStreamSynchronize(st));
+    BVH_TRY(hipGetLastError());
+    if (depth_out) *depth_out = depth;
+    return hipSuccess;
+}
+
+void bvh_free(BvhBuffers &b) {
+    if (b.nodes) (void)hipFree(b.nodes);
+    if (b.sph_sorted) (void)hipFree(b.sph_sorted);
+    if (b.aux_sorted) (void)hipFree(b.aux_sorted);
+    b = BvhBuffers{};
+}
+
+}  // namespace pt

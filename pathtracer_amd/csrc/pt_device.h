@@ -165,6 +165,27 @@ struct HitRec {
 // broadcast) and the loops carry no divergence. Within one table ascending index is
 // ascending scene order, so strict '<' keeps the first minimum; an exact tie between a
 // plane and the current best sphere is resolved by the objects' scene order.
+// Plane part of the closest-hit loop. (best_t, best) hold the best sphere so far; sph_order(best)
+// gives that sphere's scene order and is only evaluated on an exact tie.
+template <class Tbl, class OrdFn>
+__device__ __forceinline__ void closest_planes(const Tbl &tbl, const Params &P, const RayK &r, float &best_t, int &best,
+                                               OrdFn sph_order) {
+#pragma unroll 2
+    for (uint32_t j = 0; j < P.n_pl; ++j) {
+        uint32_t o = P.pl_off + j * 3u;
+        float t = plane_t(r, tbl.ld(o), tbl.ld(o + 1), tbl.ld(o + 2));
+        bool b = (t > 0.0f) & (t < best_t);
+        bool tie = (t == best_t) & (best >= 0) & (best < (int)P.n_sph);
+        if (__builtin_expect(__any(tie), 0)) {  // coincident surfaces only
+            uint32_t ord_p = __float_as_uint(tbl.ld(P.aux_off + P.n_sph + j).z);
+            uint32_t ord_s = tie ? sph_order(best) : 0u;
+            b = b | (tie & (ord_p < ord_s));
+        }
+        best_t = b ? t : best_t;
+        best = b ? (int)(P.n_sph + j) : best;
+    }
+}
+
 template <class Tbl>
 __device__ __forceinline__ HitRec closest_hit(const Tbl &tbl, const Params &P, const RayK &r) {
     float best_t = __builtin_inff();
@@ -176,40 +197,38 @@ __device__ __forceinline__ HitRec closest_hit(const Tbl &tbl, const Params &P, c
         best_t = b ? t : best_t;
         best = b ? (int)i : best;
     }
-#pragma unroll 2
-    for (uint32_t j = 0; j < P.n_pl; ++j) {
-        uint32_t o = P.pl_off + j * 3u;
-        float t = plane_t(r, tbl.ld(o), tbl.ld(o + 1), tbl.ld(o + 2));
-        bool b = (t > 0.0f) & (t < best_t);
-        bool tie = (t == best_t) & (best >= 0) & (best < (int)P.n_sph);
-        if (__builtin_expect(__any(tie), 0)) {  // coincident surfaces only
-            uint32_t ord_p = __float_as_uint(tbl.ld(P.aux_off + P.n_sph + j).z);
-            uint32_t ord_s = tie ? __float_as_uint(tbl.ld(P.aux_off + (uint32_t)best).z) : 0u;
-            b = b | (tie & (ord_p < ord_s));
-        }
-        best_t = b ? t : best_t;
-        best = b ? (int)(P.n_sph + j) : best;
-    }
+    closest_planes(tbl, P, r, best_t, best,
+                   [&](int id) { return __float_as_uint(tbl.ld(P.aux_off + (uint32_t)id).z); });
     return HitRec{best_t, best};
 }
 
 // Normal, material id and scene-order index of the winning object (sphere.rs:36-37, plane.rs:32).
-template <class Tbl>
+template <class Tbl, class SphFn>
 __device__ __forceinline__ void finish_hit(const Tbl &tbl, const Params &P, const RayK &r, HitRec h, F3 &hit, F3 &n,
-                                           uint32_t &mat, uint32_t &order) {
-    float4 aux = tbl.ld(P.aux_off + (uint32_t)h.id);  // {1/r, mat, order, 0}
+                                           uint32_t &mat, uint32_t &order, SphFn sphere_rows) {
     hit = madd(r.ro, r.rd, h.t);
-    mat = __float_as_uint(aux.y);
-    order = __float_as_uint(aux.z);
+    float4 aux;  // {1/r, mat, order, r}
     if (h.id < (int)P.n_sph) {
-        float4 s = tbl.ld(P.sph_off + (uint32_t)h.id);
+        float4 s;
+        sphere_rows(h.id, s, aux);
         n = (hit - f3(s)) * aux.x;
     } else {
+        aux = tbl.ld(P.aux_off + (uint32_t)h.id);
         uint32_t o = P.pl_off + ((uint32_t)h.id - P.n_sph) * 3u;
         float4 q0 = tbl.ld(o), q1 = tbl.ld(o + 1);
         F3 pn = F3{q0.w, q1.x, q1.y};
         n = dot(pn, r.rd) < 0.0f ? pn : -pn;
     }
+    mat = __float_as_uint(aux.y);
+    order = __float_as_uint(aux.z);
+}
+template <class Tbl>
+__device__ __forceinline__ void finish_hit(const Tbl &tbl, const Params &P, const RayK &r, HitRec h, F3 &hit, F3 &n,
+                                           uint32_t &mat, uint32_t &order) {
+    finish_hit(tbl, P, r, h, hit, n, mat, order, [&](int id, float4 &s, float4 &aux) {
+        s = tbl.ld(P.sph_off + (uint32_t)id);
+        aux = tbl.ld(P.aux_off + (uint32_t)id);
+    });
 }
 
 // renderer.rs:44-46 for NS shadow rays that leave the same point x: origin x + l*eps, unit
@@ -227,12 +246,15 @@ __device__ __forceinline__ void finish_hit(const Tbl &tbl, const Params &P, cons
 template <class Tbl, int NS, bool COUNT>
 __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, F3 x, float eps, const F3 (&l)[NS],
                                                const float (&lim)[NS], bool (&occ)[NS], uint32_t &n_sph_tests,
-                                               uint32_t &n_pl_tests) {
+                                               uint32_t &n_pl_tests, bool spheres = true) {
+    const uint32_t n_sph = spheres ? P.n_sph : 0u;  // false: the caller has tested the spheres (BVH) and set occ[]
+    if (spheres) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) occ[s] = false;
+        for (int s = 0; s < NS; ++s) occ[s] = false;
+    }
     const float eps2 = eps * eps, two_eps = 2.0f * eps;
 #pragma unroll 1
-    for (uint32_t i = 0; i < P.n_sph; ++i) {
+    for (uint32_t i = 0; i < n_sph; ++i) {
         float4 c = tbl.ld(P.sph_off + i);
         F3 X = x - f3(c);
         float K = fmaf(X.z, X.z, fmaf(X.y, X.y, fmaf(X.x, X.x, eps2 - c.w)));  // X.X - r^2 + eps^2
@@ -245,7 +267,7 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
             occ[s] = occ[s] | ((t > 0.0f) & (t * t < lim[s]));
         }
     }
-    if (COUNT) n_sph_tests += NS * P.n_sph;
+    if (COUNT) n_sph_tests += NS * n_sph;
 #pragma unroll 1
     for (uint32_t j = 0; j < P.n_pl; ++j) {
         uint32_t o = P.pl_off + j * 3u;

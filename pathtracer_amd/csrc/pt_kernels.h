@@ -4,12 +4,20 @@
 #include <stdint.h>
 
 #include "../../include/hippt.h"
+#include "pt_bvh.h"
+#include "pt_bvh_build.h"
 #include "pt_device.h"
 
 namespace pt {
 
 hipError_t launch_megakernel(const Params &P, const float4 *blob, float *accum, unsigned long long *counters,
                              bool count, bool lds, hipStream_t st);
+hipError_t launch_megakernel_bvh(const Params &P, const float4 *blob, const Bvh &bvh, float *accum,
+                                 unsigned long long *counters, bool count, hipStream_t st);
+hipError_t launch_unit_intersect_global(const Params &P, const float4 *blob, uint32_t n, const float *ro, const float *rd,
+                                        float *t, float *nn, int32_t *idx, hipStream_t st);
+hipError_t launch_unit_intersect_bvh(const Params &P, const float4 *blob, const Bvh &bvh, uint32_t n, const float *ro,
+                                     const float *rd, float *t, float *nn, int32_t *idx, hipStream_t st);
 hipError_t launch_resolve(const float *accum, uint32_t n_pixels, uint32_t spp, uint8_t *rgba, hipStream_t st);
 
 hipError_t launch_unit_intersect(const Params &P, const float4 *blob, uint32_t n, const float *ro, const float *rd,

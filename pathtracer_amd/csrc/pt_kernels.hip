@@ -7,6 +7,7 @@
 //   pt_resolve     : renderer.rs:184-191 (average, ACES, gamma, u8).
 //   pt_unit_*      : thin kernels around the same device functions, for the
 //                    1e-5 unit-parity tests.
+#include "pt_bvh.h"
 #include "pt_device.h"
 #include "pt_kernels.h"
 
@@ -22,15 +23,44 @@ __device__ __forceinline__ void lane_pixel(const Params &P, uint32_t &x, uint32_
     y = ty * 16u + (wave >> 1) * 8u + (lane >> 3);
 }
 
-template <class Tbl, bool COUNT>
+// BVH = true: spheres through the LBVH (pt_bvh.h), planes through the table loops.
+template <class Tbl, bool COUNT, bool BVH>
 struct Tracer {
     const Params &P;
     Tbl tbl;
+    Bvh bvh;
+    uint32_t *stack;  // this lane's LDS traversal stack column (BVH only), stride 256
     uint32_t cnt[HIPPT_N_COUNTERS];
 
-    __device__ __forceinline__ Tracer(const Params &p, Tbl t) : P(p), tbl(t) {
+    __device__ __forceinline__ Tracer(const Params &p, Tbl t, Bvh b, uint32_t *stk) : P(p), tbl(t), bvh(b), stack(stk) {
         if (COUNT)
             for (int i = 0; i < HIPPT_N_COUNTERS; ++i) cnt[i] = 0;
+    }
+
+    // renderer.rs:356-362
+    __device__ __forceinline__ HitRec closest(const RayK &ray) {
+        if constexpr (BVH) {
+            float best_t = __builtin_inff();
+            int best = -1;
+            uint32_t best_ord = 0xffffffffu;
+            uint32_t nt = 0;
+            bvh_closest(bvh, ray, best_t, best, best_ord, stack, 256u, nt);
+            bump(HIPPT_C_EXTEND_SPHERE_TESTS, nt);
+            closest_planes(tbl, P, ray, best_t, best, [&](int) { return best_ord; });
+            return HitRec{best_t, best};
+        } else {
+            return closest_hit(tbl, P, ray);
+        }
+    }
+    __device__ __forceinline__ void finish(const RayK &ray, HitRec h, F3 &hit, F3 &n, uint32_t &mat, uint32_t &order) {
+        if constexpr (BVH) {
+            finish_hit(tbl, P, ray, h, hit, n, mat, order, [&](int id, float4 &s, float4 &aux) {
+                s = bvh.sph[id];
+                aux = bvh.aux[id];
+            });
+        } else {
+            finish_hit(tbl, P, ray, h, hit, n, mat, order);
+        }
     }
     __device__ __forceinline__ void bump(int k, uint32_t v = 1) {
         if (COUNT) cnt[k] += v;
@@ -60,8 +90,16 @@ struct Tracer {
                 lim[s] = dist2 * 0.999f;
             }
             bump(HIPPT_C_SHADOW_RAYS, 4);
+            if constexpr (BVH) {
+#pragma unroll 1
+                for (int s = 0; s < 4; ++s) {
+                    uint32_t nt = 0;
+                    occ[s] = bvh_any(bvh, make_ray(madd(x, l[s], 1e-4f), l[s]), lim[s], stack, 256u, nt);
+                    bump(HIPPT_C_SHADOW_SPHERE_TESTS, nt);
+                }
+            }
             occluded_multi<Tbl, 4, COUNT>(tbl, P, x, 1e-4f, l, lim, occ, cnt[HIPPT_C_SHADOW_SPHERE_TESTS],
-                                          cnt[HIPPT_C_SHADOW_PLANE_TESTS]);
+                                          cnt[HIPPT_C_SHADOW_PLANE_TESTS], !BVH);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (!occ[s]) {
@@ -77,10 +115,11 @@ struct Tracer {
     }
 };
 
-template <class Tbl, bool COUNT>
+template <class Tbl, bool COUNT, bool BVH = false>
 __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x, uint32_t y, bool in_image,
-                                            float *__restrict__ accum, unsigned long long *__restrict__ counters) {
-    Tracer<Tbl, COUNT> tr(P, tbl);
+                                            float *__restrict__ accum, unsigned long long *__restrict__ counters,
+                                            Bvh bvh = Bvh{}, uint32_t *stack = nullptr) {
+    Tracer<Tbl, COUNT, BVH> tr(P, tbl, bvh, stack);
     const uint32_t pixel = y * P.width + x;
     const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
     const uint32_t pix_mixed = mix32(pixel + seed_mixed);
@@ -113,9 +152,9 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
 
         // ---- one vertex of renderer.rs:237-353 ----
         RayK ray = make_ray(ro, rd);
-        HitRec h = closest_hit(tbl, P, ray);
+        HitRec h = tr.closest(ray);
         tr.bump(HIPPT_C_EXTEND_RAYS);
-        tr.bump(HIPPT_C_EXTEND_SPHERE_TESTS, P.n_sph);
+        if (!BVH) tr.bump(HIPPT_C_EXTEND_SPHERE_TESTS, P.n_sph);
         tr.bump(HIPPT_C_EXTEND_PLANE_TESTS, P.n_pl);
         if (h.id >= 0) tr.bump(HIPPT_C_EXTEND_HITS);
 
@@ -150,7 +189,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
         } else {
             F3 hit, n;
             uint32_t mid, order;
-            finish_hit(tbl, P, ray, h, hit, n, mid, order);
+            tr.finish(ray, h, hit, n, mid, order);
             Mat m = load_mat(tbl, P.mat_off, mid);
             F3 v = -rd;
             int next_media = media;  // :301-305
@@ -245,6 +284,18 @@ __global__ __launch_bounds__(256) void pt_megakernel_global(Params P, const floa
     trace_pixel<TblGlobal, COUNT>(P, TblGlobal{blob}, x, y, in_image, accum, counters);
 }
 
+// Many-sphere scenes: spheres through the LBVH, everything else from global tables.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void pt_megakernel_bvh(Params P, const float4 *__restrict__ blob, Bvh bvh,
+                                                         float *__restrict__ accum,
+                                                         unsigned long long *__restrict__ counters) {
+    __shared__ uint32_t s_stack[BVH_STACK * 256];
+    uint32_t x, y;
+    lane_pixel(P, x, y);
+    bool in_image = (x < P.width) & (y < P.height);
+    trace_pixel<TblGlobal, COUNT, true>(P, TblGlobal{blob}, x, y, in_image, accum, counters, bvh, s_stack + threadIdx.x);
+}
+
 // renderer.rs:184-191
 __global__ __launch_bounds__(256) void pt_resolve(const float *__restrict__ accum, uint32_t n_pixels, float inv_spp,
                                                   uint8_t *__restrict__ rgba) {
@@ -266,20 +317,47 @@ __device__ __forceinline__ void st3(float *p, uint32_t i, F3 v) {
     p[3 * i + 2] = v.z;
 }
 
-__global__ void pt_unit_intersect(Params P, const float4 *__restrict__ blob, uint32_t n, const float *ro,
-                                  const float *rd, float *out_t, float *out_n, int32_t *out_idx) {
-    extern __shared__ float4 s_tbl[];
-    for (uint32_t i = threadIdx.x; i < P.blob_f4; i += blockDim.x) s_tbl[i] = blob[i];
-    __syncthreads();
+template <class Tbl>
+__device__ __forceinline__ void unit_intersect_body(const Params &P, Tbl tbl, uint32_t n, const float *ro, const float *rd,
+                                                    float *out_t, float *out_n, int32_t *out_idx) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool act = i < n;
     uint32_t j = act ? i : 0;
-    TblLds tbl{s_tbl};
     RayK r = make_ray(ld3(ro, j), ld3(rd, j));
     HitRec h = closest_hit(tbl, P, r);
     F3 hit, nn = F3{0, 0, 0};
     uint32_t mid, order = 0;
     if (h.id >= 0) finish_hit(tbl, P, r, h, hit, nn, mid, order);
+    if (act) {
+        out_t[i] = h.t;
+        st3(out_n, i, nn);
+        out_idx[i] = h.id >= 0 ? (int32_t)order : -1;
+    }
+}
+__global__ void pt_unit_intersect(Params P, const float4 *__restrict__ blob, uint32_t n, const float *ro,
+                                  const float *rd, float *out_t, float *out_n, int32_t *out_idx) {
+    extern __shared__ float4 s_tbl[];
+    for (uint32_t i = threadIdx.x; i < P.blob_f4; i += blockDim.x) s_tbl[i] = blob[i];
+    __syncthreads();
+    unit_intersect_body(P, TblLds{s_tbl}, n, ro, rd, out_t, out_n, out_idx);
+}
+__global__ void pt_unit_intersect_global(Params P, const float4 *__restrict__ blob, uint32_t n, const float *ro,
+                                         const float *rd, float *out_t, float *out_n, int32_t *out_idx) {
+    unit_intersect_body(P, TblGlobal{blob}, n, ro, rd, out_t, out_n, out_idx);
+}
+__global__ __launch_bounds__(256) void pt_unit_intersect_bvh(Params P, const float4 *__restrict__ blob, Bvh bvh, uint32_t n,
+                                                             const float *ro, const float *rd, float *out_t, float *out_n,
+                                                             int32_t *out_idx) {
+    __shared__ uint32_t s_stack[BVH_STACK * 256];
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool act = i < n;
+    uint32_t j = act ? i : 0;
+    Tracer<TblGlobal, false, true> tr(P, TblGlobal{blob}, bvh, s_stack + threadIdx.x);
+    RayK r = make_ray(ld3(ro, j), ld3(rd, j));
+    HitRec h = tr.closest(r);
+    F3 hit, nn = F3{0, 0, 0};
+    uint32_t mid, order = 0;
+    if (h.id >= 0) tr.finish(r, h, hit, nn, mid, order);
     if (act) {
         out_t[i] = h.t;
         st3(out_n, i, nn);
@@ -416,6 +494,17 @@ hipError_t launch_megakernel(const Params &P, const float4 *blob, float *accum, 
     return hipGetLastError();
 }
 
+hipError_t launch_megakernel_bvh(const Params &P, const float4 *blob, const Bvh &bvh, float *accum,
+                                 unsigned long long *counters, bool count, hipStream_t st) {
+    uint32_t tiles_y = (P.height + 15u) / 16u;
+    dim3 grid(P.tiles_x * tiles_y), block(256);
+    if (count)
+        hipLaunchKernelGGL(pt_megakernel_bvh<true>, grid, block, 0, st, P, blob, bvh, accum, counters);
+    else
+        hipLaunchKernelGGL(pt_megakernel_bvh<false>, grid, block, 0, st, P, blob, bvh, accum, counters);
+    return hipGetLastError();
+}
+
 hipError_t launch_resolve(const float *accum, uint32_t n_pixels, uint32_t spp, uint8_t *rgba, hipStream_t st) {
     hipLaunchKernelGGL(pt_resolve, dim3(grid_for(n_pixels)), dim3(256), 0, st, accum, n_pixels, 1.0f / (float)spp,
                        rgba);
@@ -426,6 +515,16 @@ hipError_t launch_unit_intersect(const Params &P, const float4 *blob, uint32_t n
                                  float *t, float *nn, int32_t *idx, hipStream_t st) {
     hipLaunchKernelGGL(pt_unit_intersect, dim3(grid_for(n)), dim3(256), (size_t)P.blob_f4 * 16, st, P, blob, n, ro, rd,
                        t, nn, idx);
+    return hipGetLastError();
+}
+hipError_t launch_unit_intersect_global(const Params &P, const float4 *blob, uint32_t n, const float *ro, const float *rd,
+                                        float *t, float *nn, int32_t *idx, hipStream_t st) {
+    hipLaunchKernelGGL(pt_unit_intersect_global, dim3(grid_for(n)), dim3(256), 0, st, P, blob, n, ro, rd, t, nn, idx);
+    return hipGetLastError();
+}
+hipError_t launch_unit_intersect_bvh(const Params &P, const float4 *blob, const Bvh &bvh, uint32_t n, const float *ro,
+                                     const float *rd, float *t, float *nn, int32_t *idx, hipStream_t st) {
+    hipLaunchKernelGGL(pt_unit_intersect_bvh, dim3(grid_for(n)), dim3(256), 0, st, P, blob, bvh, n, ro, rd, t, nn, idx);
     return hipGetLastError();
 }
 hipError_t launch_unit_occluded(const Params &P, const float4 *blob, uint32_t n, const float *ro, const float *rd,
