@@ -123,10 +123,12 @@ def main():
 
     out = None
     if rank == 0:
-        # event counts of exactly this rank's step (counting variant, untimed)
+        # event counts of exactly this rank's step (counting variant of the megakernel, untimed; the wavefront
+        # variant traces the same paths, so its events are the same)
         accum.zero_()
         ctx.render_accum_device(accum.data_ptr(), s0, SPP, seed=0, max_depth=args.max_depth,
-                                flags=args.flags | _abi.FLAG_COUNTERS, stream=stream.cuda_stream)
+                                flags=(args.flags & ~_abi.FLAG_WAVEFRONT) | _abi.FLAG_COUNTERS,
+                                stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
         cn = ctx.read_counters()
         ctx.kernel_time_ms()

@@ -183,6 +183,8 @@ struct hippt_context {
     size_t d_blob_cap = 0;
     unsigned long long *d_counters = nullptr;
     uint32_t samples = 0;
+    void *wf_ws = nullptr;  // wavefront path-state workspace (allocated on first use)
+    size_t wf_ws_bytes = 0;
     pt::BvhBuffers bvh;  // LBVH over the spheres (many-sphere scenes only)
     int bvh_depth = 0;
     // kernel timing (events on the launch stream)
@@ -222,6 +224,7 @@ int hippt_destroy(hippt_context *ctx) {
         (void)hipEventDestroy(p.second);
     }
     pt::bvh_free(ctx->bvh);
+    if (ctx->wf_ws) (void)hipFree(ctx->wf_ws);
     if (ctx->d_blob) (void)hipFree(ctx->d_blob);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -284,6 +287,21 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
         use_bvh = true;
     }
     uint64_t pixels = (uint64_t)P.width * P.height;
+    bool wavefront = (o.flags & HIPPT_FLAG_WAVEFRONT) != 0;
+    if (wavefront) {
+        if (use_bvh || !lds || count || P.n_mat > 0xffffu || P.max_depth > 31u)
+            return hippt_set_error(HIPPT_ERR_INVALID, "the wavefront variant supports LDS-sized scenes without LBVH/counters, "
+                                                      "<= 65535 materials and max_depth <= 31");
+        size_t need = pt::wf_workspace_bytes((uint32_t)pixels);
+        if (need > ctx->wf_ws_bytes) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (ctx->wf_ws) HIP_TRY(hipFree(ctx->wf_ws));
+            ctx->wf_ws = nullptr;
+            ctx->wf_ws_bytes = 0;
+            HIP_TRY(hipMalloc(&ctx->wf_ws, need));
+            ctx->wf_ws_bytes = need;
+        }
+    }
     uint64_t per = kPathsPerLaunch / pixels;
     if (per < 1) per = 1;
     while (cnt > 0) {
@@ -299,7 +317,9 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
         }
         auto &ev = ctx->ev_pool[ctx->ev_used++];
         HIP_TRY(hipEventRecord(ev.first, st));
-        if (use_bvh)
+        if (wavefront)
+            HIP_TRY(pt::wavefront_render(P, ctx->d_blob, d_accum, ctx->wf_ws, st, nullptr));
+        else if (use_bvh)
             HIP_TRY(pt::launch_megakernel_bvh(P, ctx->d_blob, bvh_view(ctx->bvh), d_accum, ctx->d_counters, count, st));
         else
             HIP_TRY(pt::launch_megakernel(P, ctx->d_blob, d_accum, ctx->d_counters, count, lds, st));
