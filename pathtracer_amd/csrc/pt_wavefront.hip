@@ -1,8 +1,11 @@
 // pt_wavefront.hip — wavefront (queue-based) variant of the trace loop, built to decide
 // "megakernel vs wavefront" from measurements (north star).
 //
-// One path slot per pixel, path state in SoA buffers in HBM (coalesced: lane i of a wave reads
-// element queue[i] of each array). Per iteration, two kernels over compacted index queues:
+// One path per pixel in flight; the path state travels WITH its queue entry, in SoA planes over
+// queue positions, so every read (entry i by lane i) and every append (base + rank in wave) is
+// coalesced. (A first version kept the state in per-pixel arrays and queued indices: its gathers
+// of 4-byte elements at compacted, i.e. scattered, indices ran 16x slower than the megakernel.)
+// Per round, two kernels over the compacted queues:
 //
 //   wf_extend : regenerate finished paths (renderer.rs:170-178), closest hit (:356-362),
 //               medium free flight (:253-264), classify; glass vertices (:307-320) are finished
@@ -20,185 +23,233 @@
 
 namespace pt {
 
-struct WfState {  // SoA over n slots (slot = pixel index)
-    float *ro, *rd, *T, *sum;  // 3 planes of n floats each: v[c * n + slot]
-    float *x, *nrm;            // hit / scatter point and normal of the pending shade vertex
-    uint32_t *rng0, *rng1;
-    uint32_t *meta;            // bit 0 alive, bits 1-5 depth, bit 6 pending vertex is a scatter, bits 8.. media+1
-    uint32_t *next_sample;     // next global sample index this slot will start
-    uint32_t *mat;             // material id of the pending shade vertex | next_media+1 << 16
-    uint32_t n;
+// A queue carries the path state of its entries, SoA over queue positions: plane k of entry i is
+// f[k * cap + i] / u[k * cap + i]. Kernels read entry i with lane-consecutive i (coalesced) and
+// append to output queues at base + rank-in-wave (coalesced per wave).
+enum { F_RO = 0, F_RD = 3, F_T = 6, F_SUM = 9, F_X = 12, F_N = 15, NF = 18 };
+enum { U_PIX = 0, U_RNG0, U_RNG1, U_META, U_NEXT, U_MAT, NU };
+// U_META: bit 0 alive, bits 1-5 depth, bit 6 pending vertex is a scatter, bits 8.. media+1
+// U_NEXT: next global sample index of this pixel; U_MAT: material of the pending vertex | (next_media+1) << 16
+struct WfQueue {
+    float *f;
+    uint32_t *u;
+    uint32_t *count;
+    uint32_t cap;
+    __device__ __forceinline__ F3 ld3(int k, uint32_t i) const {
+        return F3{f[(size_t)k * cap + i], f[(size_t)(k + 1) * cap + i], f[(size_t)(k + 2) * cap + i]};
+    }
+    __device__ __forceinline__ void st3(int k, uint32_t i, F3 v) const {
+        f[(size_t)k * cap + i] = v.x;
+        f[(size_t)(k + 1) * cap + i] = v.y;
+        f[(size_t)(k + 2) * cap + i] = v.z;
+    }
+    __device__ __forceinline__ uint32_t ldu(int k, uint32_t i) const { return u[(size_t)k * cap + i]; }
+    __device__ __forceinline__ void stu(int k, uint32_t i, uint32_t v) const { u[(size_t)k * cap + i] = v; }
 };
 
-__device__ __forceinline__ F3 ld3s(const float *p, uint32_t n, uint32_t i) { return F3{p[i], p[n + i], p[2 * n + i]}; }
-__device__ __forceinline__ void st3s(float *p, uint32_t n, uint32_t i, F3 v) {
-    p[i] = v.x;
-    p[n + i] = v.y;
-    p[2 * n + i] = v.z;
+// Reserves queue positions for the lanes of a 256-thread block: wave ballot + prefix popcount,
+// wave totals combined through LDS, ONE atomicAdd per block and queue (a per-wave atomic on the
+// single queue counter serialises: 65k same-address atomics per launch took ~0.5 ms).
+// Every thread of the block must call it. Returns this lane's position in queue 0 / queue 1.
+__device__ __forceinline__ void queue_reserve2(bool want0, uint32_t *count0, uint32_t &pos0, bool want1, uint32_t *count1,
+                                               uint32_t &pos1, uint32_t (*s_cnt)[4], uint32_t *s_base) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long m0 = __ballot(want0), m1 = __ballot(want1);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) {
+        s_cnt[0][wave] = (uint32_t)__popcll(m0);
+        s_cnt[1][wave] = (uint32_t)__popcll(m1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        uint32_t *cnt = threadIdx.x == 0 ? count0 : count1;
+        uint32_t tot = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+        s_base[threadIdx.x] = (tot && cnt) ? atomicAdd(cnt, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t off0 = 0, off1 = 0;
+    for (uint32_t w = 0; w < wave; ++w) {
+        off0 += s_cnt[0][w];
+        off1 += s_cnt[1][w];
+    }
+    pos0 = s_base[0] + off0 + (uint32_t)__popcll(m0 & below);
+    pos1 = s_base[1] + off1 + (uint32_t)__popcll(m1 & below);
+    __syncthreads();  // s_cnt / s_base are reused by the next trip
 }
 
-// Appends `slot` to queue q for the lanes with `want` set: one atomic per wave.
-__device__ __forceinline__ void queue_push(bool want, uint32_t slot, uint32_t *q, uint32_t *q_count) {
-    unsigned long long m = __ballot(want);
-    if (m == 0) return;
-    uint32_t lane = threadIdx.x & 63u;
-    uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
-    uint32_t base = 0;
-    if (lane == (uint32_t)__ffsll((long long)m) - 1u) base = atomicAdd(q_count, (uint32_t)__popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (want) q[base + rank] = slot;
-}
-
-__global__ __launch_bounds__(256) void wf_init(WfState S, uint32_t sample_begin, uint32_t *q, uint32_t *q_count) {
+__global__ __launch_bounds__(256) void wf_init(WfQueue Q, uint32_t n, uint32_t sample_begin) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= S.n) return;
-    S.meta[i] = 0;  // dead: wf_extend starts the first sample
-    S.next_sample[i] = sample_begin;
-    st3s(S.sum, S.n, i, F3{0, 0, 0});
-    q[i] = i;
-    if (i == 0) *q_count = S.n;
+    if (i >= n) return;
+    Q.stu(U_PIX, i, i);
+    Q.stu(U_META, i, 0);  // dead: wf_extend starts the first sample
+    Q.stu(U_NEXT, i, sample_begin);
+    Q.st3(F_SUM, i, F3{0, 0, 0});
+    if (i == 0) *Q.count = n;
 }
 
-__global__ __launch_bounds__(256) void wf_extend(Params P, const float4 *__restrict__ blob, WfState S,
-                                                 const uint32_t *__restrict__ q_in, const uint32_t *__restrict__ q_in_count,
-                                                 uint32_t *q_next, uint32_t *q_next_count, uint32_t *q_shade,
-                                                 uint32_t *q_shade_count) {
+__global__ __launch_bounds__(256) void wf_extend(Params P, const float4 *__restrict__ blob, WfQueue Qin, WfQueue Qnext,
+                                                 WfQueue Qshade, float *__restrict__ accum) {
     extern __shared__ float4 s_tbl[];
+    __shared__ uint32_t s_cnt[2][4], s_base[2];
     for (uint32_t i = threadIdx.x; i < P.blob_f4; i += 256u) s_tbl[i] = blob[i];
     __syncthreads();
     TblLds tbl{s_tbl};
     Tracer<TblLds, false, false> tr(P, tbl, Bvh{}, nullptr);
-    const uint32_t n = S.n, count = *q_in_count;
+    const uint32_t count = *Qin.count;
     const uint32_t s_end = P.sample_begin + P.sample_count;
     const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
     for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
         uint32_t qi = base + threadIdx.x;
         bool act = qi < count;
-        uint32_t slot = act ? q_in[qi] : 0u;
         bool to_next = false, to_shade = false;
+        uint32_t pix = 0, next = 0, depth = 0, mat_word = 0;
+        int media = -1;
+        bool alive = false, scatter = false;
+        Rng rng{0u, 1u};
+        F3 ro = F3{0, 0, 0}, rd = F3{0, 0, 1}, T = F3{1, 1, 1}, sum = F3{0, 0, 0}, x = F3{0, 0, 0}, nn = F3{0, 1, 0};
         if (act) {
-            uint32_t meta = S.meta[slot];
-            bool alive = meta & 1u;
-            uint32_t depth = (meta >> 1) & 31u;
-            int media = (int)(meta >> 8) - 1;
-            Rng rng;
-            F3 ro, rd, T;
-            if (!alive) {
-                uint32_t s = S.next_sample[slot];  // queued only while s < s_end
-                uint32_t px = slot % P.width, py = slot / P.width;
-                rng.seed(seed_mixed, mix32(slot + seed_mixed), s);
+            pix = Qin.ldu(U_PIX, qi);
+            uint32_t meta = Qin.ldu(U_META, qi);
+            next = Qin.ldu(U_NEXT, qi);
+            sum = Qin.ld3(F_SUM, qi);
+            alive = meta & 1u;
+            depth = (meta >> 1) & 31u;
+            media = (int)(meta >> 8) - 1;
+            if (!alive) {  // queued only while next < s_end
+                uint32_t px = pix % P.width, py = pix / P.width;
+                rng.seed(seed_mixed, mix32(pix + seed_mixed), next);
                 float jx = rng.gen(), jy = rng.gen(), ds = rng.gen(), dt = rng.gen();
                 camera_ray(P, px, py, jx, jy, ds, dt, ro, rd);
-                T = F3{1, 1, 1};
                 depth = 0;
                 media = -1;
                 alive = true;
-                S.next_sample[slot] = s + 1;
+                ++next;
             } else {
-                ro = ld3s(S.ro, n, slot);
-                rd = ld3s(S.rd, n, slot);
-                T = ld3s(S.T, n, slot);
-                rng.s0 = S.rng0[slot];
-                rng.s1 = S.rng1[slot];
+                ro = Qin.ld3(F_RO, qi);
+                rd = Qin.ld3(F_RD, qi);
+                T = Qin.ld3(F_T, qi);
+                rng.s0 = Qin.ldu(U_RNG0, qi);
+                rng.s1 = Qin.ldu(U_RNG1, qi);
             }
             RayK ray = make_ray(ro, rd);
             HitRec h = tr.closest(ray);
             F3 A = F3{1, 1, 1};
             float t_media = __builtin_inff();
-            Mat mm;
             if (media >= 0) {
-                mm = load_mat(tbl, P.mat_off, (uint32_t)media);
+                Mat mm = load_mat(tbl, P.mat_off, (uint32_t)media);
                 t_media = -fln(rng.gen()) * rcp(mm.density);
                 float k = -mm.density * fminf(t_media, h.t);
                 A = F3{fexp(fmaxf(1.0f - mm.color.x, 0.0f) * k), fexp(fmaxf(1.0f - mm.color.y, 0.0f) * k),
                        fexp(fmaxf(1.0f - mm.color.z, 0.0f) * k)};
             }
-            bool scatter = false;
             if (t_media < h.t) {
                 T = T * A;
-                st3s(S.x, n, slot, madd(ro, rd, t_media));
-                st3s(S.nrm, n, slot, F3{0.0f, 1.0f, 0.0f});
-                S.mat[slot] = (uint32_t)media | ((uint32_t)(media + 1) << 16);
+                x = madd(ro, rd, t_media);
+                nn = F3{0.0f, 1.0f, 0.0f};
+                mat_word = (uint32_t)media | ((uint32_t)(media + 1) << 16);
                 scatter = true;
                 to_shade = true;
             } else if (h.id < 0) {
                 alive = false;
             } else {
-                F3 hit, nn;
                 uint32_t mid, order;
-                tr.finish(ray, h, hit, nn, mid, order);
+                tr.finish(ray, h, x, nn, mid, order);
                 Mat m = load_mat(tbl, P.mat_off, mid);
                 int next_media = media;
                 if (m.density > 0.0f) next_media = (dot(-rd, nn) > 0.0f) ? (int)mid : -1;
                 T = T * A;
                 if (m.ior > 1.0f && m.metallic < 0.1f) {
                     F3 nd = glass_dir(rd, nn, m.ior, rng.gen());
-                    ro = madd(hit, nd, 1e-4f);
+                    ro = madd(x, nd, 1e-4f);
                     rd = nd;
                     media = next_media;
                     ++depth;
                     if (depth >= P.max_depth) alive = false;
                 } else {
-                    st3s(S.x, n, slot, hit);
-                    st3s(S.nrm, n, slot, nn);
-                    S.mat[slot] = mid | ((uint32_t)(next_media + 1) << 16);
+                    mat_word = mid | ((uint32_t)(next_media + 1) << 16);
                     to_shade = true;
                 }
             }
             if (!to_shade) {
-                // finished paths come back through this kernel to start their next sample
-                to_next = alive || S.next_sample[slot] < s_end;
-                if (alive) {
-                    st3s(S.ro, n, slot, ro);
-                    st3s(S.rd, n, slot, rd);
+                to_next = alive || next < s_end;  // a finished path comes back to start the pixel's next sample
+                if (!to_next) {                   // pixel done: its sum goes to the accumulator
+                    accum[3 * (size_t)pix + 0] += sum.x;
+                    accum[3 * (size_t)pix + 1] += sum.y;
+                    accum[3 * (size_t)pix + 2] += sum.z;
                 }
-            } else {
-                st3s(S.rd, n, slot, rd);  // wf_shade needs v = -rd (and rd for the scatter frame)
             }
-            if (alive) {
-                st3s(S.T, n, slot, T);
-                S.rng0[slot] = rng.s0;
-                S.rng1[slot] = rng.s1;
-            }
-            S.meta[slot] = (alive ? 1u : 0u) | (depth << 1) | (scatter ? 64u : 0u) | ((uint32_t)(media + 1) << 8);
         }
-        queue_push(to_next, slot, q_next, q_next_count);
-        queue_push(to_shade, slot, q_shade, q_shade_count);
+        uint32_t meta_out = (alive ? 1u : 0u) | (depth << 1) | (scatter ? 64u : 0u) | ((uint32_t)(media + 1) << 8);
+        uint32_t pn, ps;
+        queue_reserve2(to_next, Qnext.count, pn, to_shade, Qshade.count, ps, s_cnt, s_base);
+        if (to_next) {
+            Qnext.stu(U_PIX, pn, pix);
+            Qnext.stu(U_META, pn, meta_out);
+            Qnext.stu(U_NEXT, pn, next);
+            Qnext.st3(F_SUM, pn, sum);
+            if (alive) {
+                Qnext.st3(F_RO, pn, ro);
+                Qnext.st3(F_RD, pn, rd);
+                Qnext.st3(F_T, pn, T);
+                Qnext.stu(U_RNG0, pn, rng.s0);
+                Qnext.stu(U_RNG1, pn, rng.s1);
+            }
+        }
+        if (to_shade) {
+            Qshade.stu(U_PIX, ps, pix);
+            Qshade.stu(U_META, ps, meta_out);
+            Qshade.stu(U_NEXT, ps, next);
+            Qshade.stu(U_MAT, ps, mat_word);
+            Qshade.stu(U_RNG0, ps, rng.s0);
+            Qshade.stu(U_RNG1, ps, rng.s1);
+            Qshade.st3(F_SUM, ps, sum);
+            Qshade.st3(F_RD, ps, rd);
+            Qshade.st3(F_T, ps, T);
+            Qshade.st3(F_X, ps, x);
+            Qshade.st3(F_N, ps, nn);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void wf_shade(Params P, const float4 *__restrict__ blob, WfState S,
-                                                const uint32_t *__restrict__ q_shade, const uint32_t *__restrict__ q_shade_count,
-                                                uint32_t *q_next, uint32_t *q_next_count) {
+__global__ __launch_bounds__(256) void wf_shade(Params P, const float4 *__restrict__ blob, WfQueue Qshade, WfQueue Qnext,
+                                                float *__restrict__ accum) {
     extern __shared__ float4 s_tbl[];
+    __shared__ uint32_t s_cnt[2][4], s_base[2];
     for (uint32_t i = threadIdx.x; i < P.blob_f4; i += 256u) s_tbl[i] = blob[i];
     __syncthreads();
     TblLds tbl{s_tbl};
     Tracer<TblLds, false, false> tr(P, tbl, Bvh{}, nullptr);
-    const uint32_t n = S.n, count = *q_shade_count;
+    const uint32_t count = *Qshade.count;
     const uint32_t s_end = P.sample_begin + P.sample_count;
     for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
         uint32_t qi = base + threadIdx.x;
         bool act = qi < count;
-        uint32_t slot = act ? q_shade[qi] : 0u;
-        bool to_next = false;
+        bool to_next = false, alive = false;
+        uint32_t pix = 0, next = 0, depth = 0;
+        int media = -1;
+        Rng rng{0u, 1u};
+        F3 ro = F3{0, 0, 0}, rd = F3{0, 0, 1}, T = F3{1, 1, 1}, sum = F3{0, 0, 0};
         if (act) {
-            uint32_t meta = S.meta[slot];
-            uint32_t depth = (meta >> 1) & 31u;
+            pix = Qshade.ldu(U_PIX, qi);
+            uint32_t meta = Qshade.ldu(U_META, qi);
+            next = Qshade.ldu(U_NEXT, qi);
+            uint32_t mw = Qshade.ldu(U_MAT, qi);
+            rng.s0 = Qshade.ldu(U_RNG0, qi);
+            rng.s1 = Qshade.ldu(U_RNG1, qi);
+            depth = (meta >> 1) & 31u;
             bool scatter = meta & 64u;
-            int media = (int)(meta >> 8) - 1;
-            uint32_t mw = S.mat[slot];
+            media = (int)(meta >> 8) - 1;
             uint32_t mid = mw & 0xffffu;
             int next_media = (int)(mw >> 16) - 1;
-            F3 x = ld3s(S.x, n, slot), nn = ld3s(S.nrm, n, slot), rd = ld3s(S.rd, n, slot), T = ld3s(S.T, n, slot);
-            F3 sum = ld3s(S.sum, n, slot);
-            Rng rng{S.rng0[slot], S.rng1[slot]};
+            F3 x = Qshade.ld3(F_X, qi), nn = Qshade.ld3(F_N, qi);
+            rd = Qshade.ld3(F_RD, qi);
+            T = Qshade.ld3(F_T, qi);
+            sum = Qshade.ld3(F_SUM, qi);
             Mat m = load_mat(tbl, P.mat_off, mid);
             ShadeK sk = make_shade(nn, -rd, m);
             F3 D = tr.direct_light(x, sk, rng);
             sum = sum + T * D;
-            bool alive = true;
-            F3 ro;
+            alive = true;
             if (scatter) {
                 float ct = sample_phase_function(m.aniso, rng.gen());
                 float up = rng.gen();
@@ -235,81 +286,71 @@ __global__ __launch_bounds__(256) void wf_shade(Params P, const float4 *__restri
             }
             ++depth;
             if (depth >= P.max_depth) alive = false;
-            st3s(S.sum, n, slot, sum);
-            if (alive) {
-                st3s(S.ro, n, slot, ro);
-                st3s(S.rd, n, slot, rd);
-                st3s(S.T, n, slot, T);
-                S.rng0[slot] = rng.s0;
-                S.rng1[slot] = rng.s1;
+            to_next = alive || next < s_end;
+            if (!to_next) {
+                accum[3 * (size_t)pix + 0] += sum.x;
+                accum[3 * (size_t)pix + 1] += sum.y;
+                accum[3 * (size_t)pix + 2] += sum.z;
             }
-            S.meta[slot] = (alive ? 1u : 0u) | (depth << 1) | ((uint32_t)(media + 1) << 8);
-            to_next = alive || S.next_sample[slot] < s_end;
         }
-        queue_push(to_next, slot, q_next, q_next_count);
+        uint32_t pn, unused;
+        queue_reserve2(to_next, Qnext.count, pn, false, nullptr, unused, s_cnt, s_base);
+        if (to_next) {
+            Qnext.stu(U_PIX, pn, pix);
+            Qnext.stu(U_META, pn, (alive ? 1u : 0u) | (depth << 1) | ((uint32_t)(media + 1) << 8));
+            Qnext.stu(U_NEXT, pn, next);
+            Qnext.st3(F_SUM, pn, sum);
+            if (alive) {
+                Qnext.st3(F_RO, pn, ro);
+                Qnext.st3(F_RD, pn, rd);
+                Qnext.st3(F_T, pn, T);
+                Qnext.stu(U_RNG0, pn, rng.s0);
+                Qnext.stu(U_RNG1, pn, rng.s1);
+            }
+        }
     }
-}
-
-__global__ __launch_bounds__(256) void wf_finalize(WfState S, float *__restrict__ accum) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= S.n) return;
-    accum[3 * i + 0] += S.sum[i];
-    accum[3 * i + 1] += S.sum[S.n + i];
-    accum[3 * i + 2] += S.sum[2 * S.n + i];
 }
 
 // ---- host driver -----------------------------------------------------------------------
 size_t wf_workspace_bytes(uint32_t n_pixels) {
-    // 18 float planes + 5 uint planes + 3 queues + counters
-    return (size_t)n_pixels * 4 * (18 + 5 + 3) + 4096 + 32 * 256;
+    // three queues x (NF float + NU uint planes) + counters
+    size_t per_queue = ((size_t)n_pixels * 4 * (NF + NU) + 511) & ~(size_t)255;
+    return 3 * per_queue + 4096;
 }
 
-// Renders P.sample_count samples per pixel into accum (adds). Workspace from wf_workspace_bytes().
-// iterations_out / launches_out: bookkeeping for the bench.
+// Renders P.sample_count samples per pixel and adds each pixel's radiance sum into accum.
+// Workspace from wf_workspace_bytes(). iterations_out: number of extend/shade rounds run.
 hipError_t wavefront_render(const Params &P, const float4 *blob, float *accum, void *workspace, hipStream_t st,
                             uint32_t *iterations_out) {
     const uint32_t n = P.width * P.height;
     uint8_t *w = (uint8_t *)workspace;
-    auto take = [&](size_t bytes) {
-        void *p = w;
-        w += (bytes + 255) & ~(size_t)255;
-        return p;
-    };
-    uint32_t *counters = (uint32_t *)take(4096);  // [0],[1]: extend queue counts (ping-pong), [2]: shade queue count
-    WfState S;
-    S.n = n;
-    S.ro = (float *)take((size_t)n * 12);
-    S.rd = (float *)take((size_t)n * 12);
-    S.T = (float *)take((size_t)n * 12);
-    S.sum = (float *)take((size_t)n * 12);
-    S.x = (float *)take((size_t)n * 12);
-    S.nrm = (float *)take((size_t)n * 12);
-    S.rng0 = (uint32_t *)take((size_t)n * 4);
-    S.rng1 = (uint32_t *)take((size_t)n * 4);
-    S.meta = (uint32_t *)take((size_t)n * 4);
-    S.next_sample = (uint32_t *)take((size_t)n * 4);
-    S.mat = (uint32_t *)take((size_t)n * 4);
-    uint32_t *q[2] = {(uint32_t *)take((size_t)n * 4), (uint32_t *)take((size_t)n * 4)};
-    uint32_t *q_shade = (uint32_t *)take((size_t)n * 4);
-
+    uint32_t *counters = (uint32_t *)w;  // [0],[1]: ray queue counts (ping-pong), [2]: shade queue count
+    w += 4096;
+    size_t per_queue = ((size_t)n * 4 * (NF + NU) + 511) & ~(size_t)255;
+    WfQueue Q[3];
+    for (int k = 0; k < 3; ++k) {
+        Q[k].f = (float *)(w + per_queue * k);
+        Q[k].u = (uint32_t *)(w + per_queue * k + (size_t)n * 4 * NF);
+        Q[k].count = &counters[k];
+        Q[k].cap = n;
+    }
     const unsigned blocks_all = (n + 255) / 256;
     const unsigned grid = std::min(blocks_all, 256u * 8u);  // grid-stride over the queues
     const size_t shmem = (size_t)P.blob_f4 * sizeof(float4);
     hipError_t e;
     if ((e = hipMemsetAsync(counters, 0, 4096, st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(wf_init, dim3(blocks_all), dim3(256), 0, st, S, P.sample_begin, q[0], &counters[0]);
-    // every sample needs at most max_depth extend iterations; finished slots leave the queues, so
-    // the queue is empty after at most sample_count * max_depth iterations. Poll the count now and then.
+    if (P.sample_count == 0) return hipSuccess;
+    hipLaunchKernelGGL(wf_init, dim3(blocks_all), dim3(256), 0, st, Q[0], n, P.sample_begin);
+    // every sample needs at most max_depth rounds, so the ray queue is empty after at most
+    // sample_count * max_depth rounds; the count is polled every 64 rounds to stop early.
     const uint32_t max_iter = P.sample_count * P.max_depth + 1;
     uint32_t it = 0;
     int cur = 0;
     for (; it < max_iter; ++it) {
         if ((e = hipMemsetAsync(&counters[1 - cur], 0, 4, st)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(&counters[2], 0, 4, st)) != hipSuccess) return e;
-        hipLaunchKernelGGL(wf_extend, dim3(grid), dim3(256), shmem, st, P, blob, S, q[cur], &counters[cur], q[1 - cur],
-                           &counters[1 - cur], q_shade, &counters[2]);
-        hipLaunchKernelGGL(wf_shade, dim3(grid), dim3(256), shmem, st, P, blob, S, q_shade, &counters[2], q[1 - cur],
-                           &counters[1 - cur]);
+        hipLaunchKernelGGL(wf_extend, dim3(grid), dim3(256), shmem, st, P, blob, Q[cur], Q[1 - cur], Q[2], accum);
+        hipLaunchKernelGGL(wf_shade, dim3(grid), dim3(256), shmem, st, P, blob, Q[2], Q[1 - cur], accum);
         cur = 1 - cur;
         if ((it & 63u) == 63u) {
             uint32_t left = 0;
@@ -321,7 +362,6 @@ hipError_t wavefront_render(const Params &P, const float4 *blob, float *accum, v
             }
         }
     }
-    hipLaunchKernelGGL(wf_finalize, dim3(blocks_all), dim3(256), 0, st, S, accum);
     if (iterations_out) *iterations_out = it;
     return hipGetLastError();
 }
