@@ -20,8 +20,8 @@ for k, c in sorted(tot.items()):
         print(f"   {n:32s} {v:.6g}")
     g = c.get
     if g("SQ_INSTS_VALU") and g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
-        # SQ_ACTIVE_INST_VALU counts quad-cycles; a wave64 VALU op occupies 2 SIMD-32 cycles (4 for transcendental)
-        print(f"   -> active lanes per VALU instruction : {g('SQ_THREAD_CYCLES_VALU') / g('SQ_ACTIVE_INST_VALU') / 4 * 1:.2f} (x/64 utilisation; derived)")
+        lanes = g('SQ_THREAD_CYCLES_VALU') / g('SQ_INSTS_VALU')
+        print(f"   -> active lanes per VALU instruction : {lanes:.2f} of 64 ({lanes / 64:.3f})")
     if g("SQ_INSTS_VALU") and g("SQ_WAVES"):
         print(f"   -> VALU instructions per wave       : {g('SQ_INSTS_VALU') / g('SQ_WAVES'):.0f}")
     if g("SQ_ACTIVE_INST_VALU") and g("SQ_WAVE_CYCLES"):
