@@ -6,10 +6,11 @@
 #include <cstdio>
 #include <vector>
 
-#define ITER 4096
+#define ITER 32768
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(float *out, float a, float b) {
+__global__ __launch_bounds__(256) void k(float *out, float a, float b, unsigned long long *cyc) {
+    unsigned long long c0 = __builtin_readcyclecounter();  // s_memtime: shader-clock ticks
     float x0 = threadIdx.x * 1e-3f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
     for (int i = 0; i < ITER; ++i) {
         if (MODE == 0) {  // 8 independent fma chains
@@ -50,6 +51,39 @@ __global__ __launch_bounds__(256) void k(float *out, float a, float b) {
                          "v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n v_pk_mul_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %5\n"
                          : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pa), "v"(pb));
             x0 = p0.x; x1 = p0.y; x2 = p1.x; x3 = p1.y; x4 = p2.x; x5 = p2.y; x6 = p3.x; x7 = p3.y;
+        } else if (MODE == 9) {  // v_cmp into vcc only
+            asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_cmp_lt_f32 vcc, %2, %8\n v_cmp_lt_f32 vcc, %3, %8\n"
+                         "v_cmp_lt_f32 vcc, %4, %8\n v_cmp_lt_f32 vcc, %5, %8\n v_cmp_lt_f32 vcc, %6, %8\n v_cmp_lt_f32 vcc, %7, %8\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "vcc");
+        } else if (MODE == 10) {  // v_cmp (VOP3) into distinct SGPR pairs
+            asm volatile("v_cmp_lt_f32 s[20:21], %0, %8\n v_cmp_lt_f32 s[22:23], %1, %8\n v_cmp_lt_f32 s[24:25], %2, %8\n v_cmp_lt_f32 s[26:27], %3, %8\n"
+                         "v_cmp_lt_f32 s[28:29], %4, %8\n v_cmp_lt_f32 s[30:31], %5, %8\n v_cmp_lt_f32 s[32:33], %6, %8\n v_cmp_lt_f32 s[34:35], %7, %8\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b)
+                         : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35");
+        } else if (MODE == 11) {  // v_min / v_max
+            asm volatile("v_min_f32 %0, %0, %8\n v_max_f32 %1, %1, %9\n v_min_f32 %2, %2, %8\n v_max_f32 %3, %3, %9\n"
+                         "v_min_f32 %4, %4, %8\n v_max_f32 %5, %5, %9\n v_min_f32 %6, %6, %8\n v_max_f32 %7, %7, %9\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+        } else if (MODE == 12) {  // v_min3 / v_max3 / v_med3
+            asm volatile("v_min3_f32 %0, %0, %8, %9\n v_max3_f32 %1, %1, %8, %9\n v_med3_f32 %2, %2, %8, %9\n v_min3_f32 %3, %3, %8, %9\n"
+                         "v_max3_f32 %4, %4, %8, %9\n v_med3_f32 %5, %5, %8, %9\n v_min3_f32 %6, %6, %8, %9\n v_max3_f32 %7, %7, %8, %9\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+        } else if (MODE == 13) {  // v_cndmask only (vcc constant)
+            asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %9, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %9, vcc\n"
+                         "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %9, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %9, vcc\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "vcc");
+        } else if (MODE == 14) {  // VOP3 encodings with |abs| / neg modifiers
+            asm volatile("v_mul_f32 %0, |%0|, %8\n v_sub_f32 %1, -%1, %9\n v_max_f32 %2, |%2|, |%8|\n v_fma_f32 %3, -%3, %8, %9\n"
+                         "v_mul_f32 %4, |%4|, %8\n v_sub_f32 %5, -%5, %9\n v_max_f32 %6, |%6|, |%8|\n v_fma_f32 %7, -%7, %8, %9\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+        } else if (MODE == 15) {  // 32-bit literal operands (v_fmamk / v_add with literal)
+            asm volatile("v_fmamk_f32 %0, %0, 0x3951b717, %8\n v_add_f32 %1, 0x38d1b717, %1\n v_fmamk_f32 %2, %2, 0x3951b717, %8\n v_add_f32 %3, 0x38d1b717, %3\n"
+                         "v_fmamk_f32 %4, %4, 0x3951b717, %8\n v_add_f32 %5, 0x38d1b717, %5\n v_fmamk_f32 %6, %6, 0x3951b717, %8\n v_add_f32 %7, 0x38d1b717, %7\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+        } else if (MODE == 16) {  // v_fmac (VOP2) independent
+            asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n"
+                         "v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
         } else if (MODE == 6) {  // 4 x (fma with one SGPR operand), independent
             asm volatile("v_fma_f32 %0, %0, %8, %1\n v_fma_f32 %1, %1, %8, %2\n v_fma_f32 %2, %2, %8, %3\n v_fma_f32 %3, %3, %8, %4\n"
                          "v_fma_f32 %4, %4, %8, %5\n v_fma_f32 %5, %5, %8, %6\n v_fma_f32 %6, %6, %8, %7\n v_fma_f32 %7, %7, %8, %0\n"
@@ -57,44 +91,63 @@ __global__ __launch_bounds__(256) void k(float *out, float a, float b) {
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+    unsigned long long c1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = c1 - c0;
 }
 
 template <int MODE>
-void run(const char *name, float *d) {
+void run(const char *name, float *d, unsigned long long *dc) {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     int cus = prop.multiProcessorCount;
-    for (int waves = 1; waves <= 8; waves *= 2) {
+    const int wlist[] = {1, 5, 8};
+    for (int waves : wlist) {
         int blocks = cus * waves;  // one 256-thread block = 1 wave on each of the CU's 4 SIMDs
         hipEvent_t a, b;
         hipEventCreate(&a);
         hipEventCreate(&b);
-        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 1.0001f, 0.5f);
+        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 1.0001f, 0.5f, dc);
         hipEventRecord(a);
-        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 1.0001f, 0.5f);
+        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 1.0001f, 0.5f, dc);
         hipEventRecord(b);
         hipEventSynchronize(b);
         float ms;
         hipEventElapsedTime(&ms, a, b);
         double insts_per_simd = 5.0 * waves * ITER * 8.0;  // wave-instructions issued on one SIMD
         double sec = ms * 1e-3;
-        printf("%-28s waves/SIMD=%d  %.3f wave-inst/ns/SIMD  => %.2f cycles/inst at 2.4 GHz  (%.1f Ginst/s chip)\n", name, waves,
-               insts_per_simd / (sec * 1e9), 2.4 / (insts_per_simd / (sec * 1e9)), insts_per_simd * cus * 4 / sec / 1e9);
+        // in-kernel view: mean shader-clock ticks one wave spent, shared by `waves` waves on its SIMD
+        std::vector<unsigned long long> hc(blocks * 4);
+        hipMemcpy(hc.data(), dc, hc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double mean = 0, mx = 0;
+        for (auto v : hc) { mean += (double)v; if ((double)v > mx) mx = (double)v; }
+        mean /= hc.size();
+        printf("%-30s waves/SIMD=%d  %.3f wave-inst/ns/SIMD (events)  | s_memtime: mean %.0f max %.0f ticks per wave => %.2f ticks/inst/SIMD (max / insts on the SIMD); "
+               "kernel %.1f us\n", name, waves, insts_per_simd / (sec * 1e9), mean, mx, mx / (double(ITER) * 8.0 * waves), ms * 1e3 / 5);
     }
 }
 
 int main() {
     float *d;
+    unsigned long long *dc;
     hipMalloc(&d, 256 * 8 * 2048 * sizeof(float));
-    run<0>("fma independent", d);
-    run<1>("fma dependent chain", d);
-    run<2>("mul/add independent", d);
-    run<3>("cmp+cndmask", d);
-    run<4>("rcp/sqrt", d);
-    run<5>("int xor/shift/cvt", d);
-    run<6>("fma chain w/ sgpr operand", d);
-    run<7>("v_pk_fma_f32 (8 inst/iter)", d);
-    run<8>("v_pk_mul/add_f32 (8 inst/iter)", d);
+    hipMalloc(&dc, 256 * 8 * 4 * sizeof(unsigned long long));
+    run<0>("fma independent", d, dc);
+    run<1>("fma dependent chain", d, dc);
+    run<2>("mul/add independent", d, dc);
+    run<3>("cmp+cndmask", d, dc);
+    run<4>("rcp/sqrt", d, dc);
+    run<5>("int xor/shift/cvt", d, dc);
+    run<6>("fma chain w/ sgpr operand", d, dc);
+    run<7>("v_pk_fma_f32 (8 inst/iter)", d, dc);
+    run<8>("v_pk_mul/add_f32 (8 inst/iter)", d, dc);
+    run<9>("v_cmp -> vcc", d, dc);
+    run<10>("v_cmp (VOP3) -> sgpr pairs", d, dc);
+    run<11>("v_min/v_max", d, dc);
+    run<12>("v_min3/max3/med3", d, dc);
+    run<13>("v_cndmask (vcc fixed)", d, dc);
+    run<14>("VOP3 abs/neg modifiers", d, dc);
+    run<15>("32-bit literal operands", d, dc);
+    run<16>("v_fmac_f32 (VOP2)", d, dc);
     hipFree(d);
     return 0;
 }
