@@ -159,6 +159,62 @@ struct HitRec {
     int id;  // index into the aux table (spheres first, then planes), -1 = miss
 };
 
+// The WINNING object's t, hit point and normal are recomputed once per ray with the reference's own
+// operation order and roundings (no FMA contraction, sqrt and divide corrected to the rounded result):
+// sphere.rs:26-37, plane.rs:25-28, renderer.rs:295. The candidate tests above may fuse and use v_rcp
+// (they only rank the objects); but t of a small far sphere is a cancellation (disc = b^2 - 4ac with
+// b^2 ~ 10^3, disc ~ r^2), so any re-association moves t by ~1e-4 and the normal by ~1e-2, after which
+// a path among many spheres takes a different course. With the reference's rounding the hit record is
+// bit-identical to the CPU renderer's in all but threshold cases, at ~30 instructions per ray.
+// n / d and sqrt(x) from v_rcp / v_rsq plus one residual correction (Markstein): the correctly rounded
+// result in all but a vanishing fraction of cases, at 4-5 instructions instead of the ~12 of hipcc's
+// IEEE expansions (which also handle denormal scaling that cannot occur here). x <= 0 gives NaN.
+__device__ __forceinline__ float div_cr(float n, float d) {
+    float rc = rcp(d);
+    float q = n * rc;
+    return fmaf(fmaf(-q, d, n), rc, q);
+}
+__device__ __forceinline__ float sqrt_cr(float x) {
+    float y = rsq(x);
+    float s = x * y;
+    return fmaf(fmaf(-s, s, x), 0.5f * y, s);
+}
+__device__ __forceinline__ float sphere_t_ref(F3 ro, F3 rd, float4 c_r2) {
+#pragma clang fp contract(off)
+    float ox = ro.x - c_r2.x, oy = ro.y - c_r2.y, oz = ro.z - c_r2.z;
+    float a = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z;
+    float b = 2.0f * (ox * rd.x + oy * rd.y + oz * rd.z);
+    float c = (ox * ox + oy * oy + oz * oz) - c_r2.w;
+    float disc = b * b - 4.0f * a * c;
+    return div_cr(-b - sqrt_cr(disc), 2.0f * a);
+}
+__device__ __forceinline__ float plane_t_ref(F3 ro, F3 rd, float4 q0, float4 q1) {
+#pragma clang fp contract(off)
+    float nx = q0.w, ny = q1.x, nz = q1.y;
+    float denom = nx * rd.x + ny * rd.y + nz * rd.z;
+    float num = (q0.x - ro.x) * nx + (q0.y - ro.y) * ny + (q0.z - ro.z) * nz;
+    return div_cr(num, denom);
+}
+// ro + rd * t with two roundings per component (renderer.rs:272,295; sphere.rs:36)
+__device__ __forceinline__ F3 point_at_ref(F3 ro, F3 rd, float t) {
+#pragma clang fp contract(off)
+    return F3{ro.x + rd.x * t, ro.y + rd.y * t, ro.z + rd.z * t};
+}
+// Replaces h.t by the reference-rounded value (kept if the refined value fails the hit condition, which
+// can only happen on a threshold).
+template <class Tbl, class SphRow>
+__device__ __forceinline__ void refine_hit(const Tbl &tbl, const Params &P, F3 ro, F3 rd, HitRec &h, SphRow sphere_row) {
+    if (h.id < 0) return;
+    float te;
+    if (h.id < (int)P.n_sph) {
+        te = sphere_t_ref(ro, rd, sphere_row(h.id));
+    } else {
+        uint32_t o = P.pl_off + ((uint32_t)h.id - P.n_sph) * 3u;
+        te = plane_t_ref(ro, rd, tbl.ld(o), tbl.ld(o + 1));
+    }
+    if (te > 0.0f && te < __builtin_inff()) h.t = te;
+}
+
 
 // renderer.rs:356-362: closest hit, first minimum in scene order. The object index is
 // wave-uniform, so every table read is a uniform-address read (scalar loads / LDS
@@ -199,14 +255,16 @@ __device__ __forceinline__ HitRec closest_hit(const Tbl &tbl, const Params &P, c
     }
     closest_planes(tbl, P, r, best_t, best,
                    [&](int id) { return __float_as_uint(tbl.ld(P.aux_off + (uint32_t)id).z); });
-    return HitRec{best_t, best};
+    HitRec h{best_t, best};
+    refine_hit(tbl, P, r.ro, r.rd, h, [&](int id) { return tbl.ld(P.sph_off + (uint32_t)id); });
+    return h;
 }
 
 // Normal, material id and scene-order index of the winning object (sphere.rs:36-37, plane.rs:32).
 template <class Tbl, class SphFn>
 __device__ __forceinline__ void finish_hit(const Tbl &tbl, const Params &P, const RayK &r, HitRec h, F3 &hit, F3 &n,
                                            uint32_t &mat, uint32_t &order, SphFn sphere_rows) {
-    hit = madd(r.ro, r.rd, h.t);
+    hit = point_at_ref(r.ro, r.rd, h.t);
     float4 aux;  // {1/r, mat, order, r}
     if (h.id < (int)P.n_sph) {
         float4 s;

@@ -81,7 +81,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
 
         if (t_media < h.t) {  // :269 scatter inside the medium
             tr.bump(HIPPT_C_SCATTER_EVENTS);
-            F3 xs = madd(ro, rd, t_media);
+            F3 xs = point_at_ref(ro, rd, t_media);
             ShadeK sk = make_shade(F3{0.0f, 1.0f, 0.0f}, -rd, mm);  // :273 (fixed "up" normal, quirk Q11)
             F3 D = tr.direct_light(xs, sk, rng);
             float ct = sample_phase_function(mm.aniso, rng.gen());

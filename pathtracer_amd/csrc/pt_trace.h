@@ -31,7 +31,9 @@ struct Tracer {
             bvh_closest(bvh, ray, best_t, best, best_ord, stack, 256u, nt);
             bump(HIPPT_C_EXTEND_SPHERE_TESTS, nt);
             closest_planes(tbl, P, ray, best_t, best, [&](int) { return best_ord; });
-            return HitRec{best_t, best};
+            HitRec h{best_t, best};
+            refine_hit(tbl, P, ray.ro, ray.rd, h, [&](int id) { return bvh.sph[id]; });
+            return h;
         } else {
             return closest_hit(tbl, P, ray);
         }

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void wf_extend(Params P, const float4 *__restr
             }
             if (t_media < h.t) {
                 T = T * A;
-                x = madd(ro, rd, t_media);
+                x = point_at_ref(ro, rd, t_media);
                 nn = F3{0.0f, 1.0f, 0.0f};
                 mat_word = (uint32_t)media | ((uint32_t)(media + 1) << 16);
                 scatter = true;

@@ -34,11 +34,14 @@ def test_intersect(hip, oracle, example_scene):
     hit = same & (i_o >= 0)
     assert hit.sum() > N // 2
     e_t = rel_err(t_h[hit], t_o[hit])
-    # sphere roots with a nearly vanishing discriminant are cancellation-limited
-    assert np.quantile(e_t, 0.999) < TOL, np.quantile(e_t, 0.999)
-    assert (e_t < 1e-3).all()
+    # the winner's t, hit point and normal are recomputed with the reference's own roundings
+    # (pt_device.h: refine_hit), so the hit record is bit-identical except for a vanishing fraction of
+    # division / square-root corrections
+    assert (t_h[hit] == t_o[hit]).mean() > 0.999
+    assert (n_h[hit] == n_o[hit]).all(axis=1).mean() > 0.999
+    assert e_t.max() < TOL, e_t.max()
     e_n = rel_err_vec(n_h[hit], n_o[hit])
-    assert np.quantile(e_n, 0.999) < TOL
+    assert e_n.max() < TOL
     miss = same & (i_o < 0)
     assert np.isinf(t_h[miss]).all()
 
