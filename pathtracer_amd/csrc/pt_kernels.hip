@@ -68,50 +68,56 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
         bool done = false;  // path ends after this vertex
         F3 A = F3{1, 1, 1};
         float t_media = __builtin_inff();
-        Mat mm;
+        Mat m;  // the medium's material, then the material shaded at this vertex
         if (media >= 0) {  // only media with density > 0 are ever entered (:301)
-            mm = load_mat(tbl, P.mat_off, (uint32_t)media);
+            m = load_mat(tbl, P.mat_off, (uint32_t)media);
             tr.bump(HIPPT_C_MEDIUM_VERTICES);
-            t_media = -fln(rng.gen()) * rcp(mm.density);  // :257
+            t_media = -fln(rng.gen()) * rcp(m.density);  // :257
             float d = fminf(t_media, h.t);
-            float k = -mm.density * d;
-            A = F3{fexp(fmaxf(1.0f - mm.color.x, 0.0f) * k), fexp(fmaxf(1.0f - mm.color.y, 0.0f) * k),
-                   fexp(fmaxf(1.0f - mm.color.z, 0.0f) * k)};  // :261-262
+            float k = -m.density * d;
+            A = F3{fexp(fmaxf(1.0f - m.color.x, 0.0f) * k), fexp(fmaxf(1.0f - m.color.y, 0.0f) * k),
+                   fexp(fmaxf(1.0f - m.color.z, 0.0f) * k)};  // :261-262
         }
 
-        if (t_media < h.t) {  // :269 scatter inside the medium
+        // Classify the vertex; scatter points and opaque surfaces then share ONE next-event-estimation
+        // block, so a wave whose lanes are split between fog and surfaces runs it once, not twice.
+        int kind = 0;  // 0: miss or glass (no NEE), 1: opaque surface, 2: scatter point inside the medium
+        F3 x = F3{0, 0, 0}, n = F3{0.0f, 1.0f, 0.0f};  // :273: scatter points shade with a fixed "up" normal (Q11)
+        int next_media = media;
+        if (t_media < h.t) {  // :269
             tr.bump(HIPPT_C_SCATTER_EVENTS);
-            F3 xs = point_at_ref(ro, rd, t_media);
-            ShadeK sk = make_shade(F3{0.0f, 1.0f, 0.0f}, -rd, mm);  // :273 (fixed "up" normal, quirk Q11)
-            F3 D = tr.direct_light(xs, sk, rng);
-            float ct = sample_phase_function(mm.aniso, rng.gen());
-            float up = rng.gen();
-            F3 nd = scatter_dir(rd, ct, up);
+            x = point_at_ref(ro, rd, t_media);
             T = T * A;
-            sum = sum + T * D;  // :181 + :285, added straight into the pixel sum
-            ro = xs;  // no epsilon (:285)
-            rd = nd;
+            kind = 2;
         } else if (h.id < 0) {  // :291 sky is black
             done = true;
         } else {
-            F3 hit, n;
             uint32_t mid, order;
-            tr.finish(ray, h, hit, n, mid, order);
-            Mat m = load_mat(tbl, P.mat_off, mid);
-            F3 v = -rd;
-            int next_media = media;  // :301-305
-            if (m.density > 0.0f) next_media = (dot(v, n) > 0.0f) ? (int)mid : -1;
+            tr.finish(ray, h, x, n, mid, order);
+            m = load_mat(tbl, P.mat_off, mid);
+            if (m.density > 0.0f) next_media = (dot(-rd, n) > 0.0f) ? (int)mid : -1;  // :301-305
             T = T * A;
             if (m.ior > 1.0f && m.metallic < 0.1f) {  // :307 glass
                 tr.bump(HIPPT_C_GLASS_VERTICES);
                 F3 nd = glass_dir(rd, n, m.ior, rng.gen());
-                ro = madd(hit, nd, 1e-4f);
+                ro = madd(x, nd, 1e-4f);
                 rd = nd;
                 media = next_media;
+            } else {
+                kind = 1;
+            }
+        }
+
+        if (kind != 0) {
+            ShadeK sk = make_shade(n, -rd, m);
+            F3 D = tr.direct_light(x, sk, rng);
+            sum = sum + T * D;  // :181 + :285 / :325, added straight into the pixel sum
+            if (kind == 2) {
+                float ct = sample_phase_function(m.aniso, rng.gen());
+                float up = rng.gen();
+                rd = scatter_dir(rd, ct, up);
+                ro = x;  // no epsilon (:285)
             } else {  // :323 opaque
-                ShadeK sk = make_shade(n, v, m);
-                F3 D = tr.direct_light(hit, sk, rng);
-                sum = sum + T * D;
                 float p = fmaxf(fmaxf(m.color.x, m.color.y), m.color.z);  // :327
                 bool cont = depth < 2u;
                 if (!cont) cont = rng.gen() < p;  // drawn only when depth >= 2 (:328)
@@ -132,7 +138,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
                     if (c > 0.0f) {  // :343
                         float w = depth >= 2u ? c * rcp(p) : c;
                         T = T * f * w;
-                        ro = madd(hit, nd, 1e-4f);
+                        ro = madd(x, nd, 1e-4f);
                         rd = nd;
                         media = next_media;
                     } else {
