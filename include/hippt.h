@@ -204,6 +204,33 @@ int hippt_read_counters(hippt_context *ctx, uint64_t *counters);
  * number. Synchronises the stream. */
 int hippt_kernel_time_ms(hippt_context *ctx, double *total_ms, uint32_t *launches);
 
+/* ---- progressive / checkpointed accumulation ------------------------------
+ * The analogue of the reference's dispatch loop with host-side accumulation
+ * (src/gpu_renderer.rs:94-183): render a sample range, add it to an accumulator the
+ * caller keeps on the HOST, and go on; any sample count and any chunk size (the
+ * reference over-renders its last dispatch, gpu_renderer.rs:98-102 — not reproduced).
+ * Used for long jobs such as the 131072-spp showcase render: the host accumulator plus
+ * the number of samples done is a complete checkpoint. */
+
+/* Renders samples [opts->sample_begin, +sample_count) of every pixel of the context's
+ * scene into a context-owned device buffer and ADDS the per-pixel sums to host_accum
+ * (width*height*3 floats, RGB interleaved, row 0 = top). Blocking. */
+int hippt_render_accum_add_f32(hippt_context *ctx, const hippt_options *opts, float *host_accum);
+
+/* Average / ACES / gamma / quantise (src/renderer.rs:184-191) of a HOST accumulator of
+ * n_pixels*3 floats through the same device kernel as hippt_resolve_device. */
+int hippt_resolve_f32(hippt_context *ctx, const float *host_accum, uint32_t n_pixels, uint32_t spp,
+                      uint8_t *out_rgba);
+
+/* Checkpoint file: 32-byte header {"HIPPTAC1", width, height, samples_done, seed, 0, 0}
+ * (little-endian u32) followed by width*height*3 f32 radiance sums. save writes to
+ * path + ".tmp" and renames, so a killed job never leaves a truncated checkpoint. load
+ * fails with HIPPT_ERR_INVALID if the file's size does not match width x height. */
+int hippt_checkpoint_save(const char *path, const float *accum, uint32_t width, uint32_t height,
+                          uint32_t samples_done, uint32_t seed);
+int hippt_checkpoint_load(const char *path, float *accum, uint32_t width, uint32_t height,
+                          uint32_t *samples_done, uint32_t *seed);
+
 /* ---- host-side scene plumbing (src/scene.rs, src/main.rs) ---------------- */
 
 typedef struct hippt_scene_file hippt_scene_file; /* owns the tables */

@@ -77,6 +77,7 @@ EXPORTED_SYMBOLS = (
     "hippt_test_occluded", "hippt_test_nee_eval", "hippt_test_ggx_terms", "hippt_test_ggx_sample",
     "hippt_test_diffuse_sample", "hippt_test_glass", "hippt_test_hg", "hippt_test_camera_ray",
     "hippt_test_tonemap", "hippt_test_rng",
+    "hippt_render_accum_add_f32", "hippt_resolve_f32", "hippt_checkpoint_save", "hippt_checkpoint_load",
 )
 
 _lib = None

@@ -187,6 +187,8 @@ struct hippt_context {
     size_t wf_ws_bytes = 0;
     pt::BvhBuffers bvh;  // LBVH over the spheres (many-sphere scenes only)
     int bvh_depth = 0;
+    void *chunk_buf = nullptr;  // device staging of the progressive entry points
+    size_t chunk_bytes = 0;
     // kernel timing (events on the launch stream)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
@@ -225,6 +227,7 @@ int hippt_destroy(hippt_context *ctx) {
     }
     pt::bvh_free(ctx->bvh);
     if (ctx->wf_ws) (void)hipFree(ctx->wf_ws);
+    if (ctx->chunk_buf) (void)hipFree(ctx->chunk_buf);
     if (ctx->d_blob) (void)hipFree(ctx->d_blob);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -336,6 +339,51 @@ int hippt_resolve_device(hippt_context *ctx, const float *d_accum, uint32_t spp,
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     HIP_TRY(pt::launch_resolve(d_accum, ctx->scene.P.width * ctx->scene.P.height, spp, d_rgba, st));
+    return HIPPT_OK;
+}
+
+static int chunk_reserve(hippt_context *ctx, size_t bytes) {
+    if (bytes <= ctx->chunk_bytes) return HIPPT_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->chunk_buf) HIP_TRY(hipFree(ctx->chunk_buf));
+    ctx->chunk_buf = nullptr;
+    ctx->chunk_bytes = 0;
+    HIP_TRY(hipMalloc(&ctx->chunk_buf, bytes));
+    ctx->chunk_bytes = bytes;
+    return HIPPT_OK;
+}
+
+int hippt_render_accum_add_f32(hippt_context *ctx, const hippt_options *opts, float *host_accum) {
+    if (!ctx || !ctx->has_scene) return hippt_set_error(HIPPT_ERR_INVALID, "no scene set");
+    if (!host_accum) return hippt_set_error(HIPPT_ERR_INVALID, "host_accum is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t n = (size_t)ctx->scene.P.width * ctx->scene.P.height * 3;
+    int rc = chunk_reserve(ctx, n * sizeof(float));
+    if (rc) return rc;
+    float *d = (float *)ctx->chunk_buf;
+    HIP_TRY(hipMemsetAsync(d, 0, n * sizeof(float), ctx->stream));
+    rc = hippt_render_accum_device(ctx, opts, d, nullptr);
+    if (rc) return rc;
+    std::vector<float> part(n);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(part.data(), d, n * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) host_accum[i] += part[i];  // gpu_renderer.rs:175-179
+    return HIPPT_OK;
+}
+
+int hippt_resolve_f32(hippt_context *ctx, const float *host_accum, uint32_t n_pixels, uint32_t spp, uint8_t *out_rgba) {
+    if (!ctx) return hippt_set_error(HIPPT_ERR_INVALID, "ctx is NULL");
+    if (!host_accum || !out_rgba || !n_pixels || !spp) return hippt_set_error(HIPPT_ERR_INVALID, "bad resolve arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t fb = (size_t)n_pixels * 12, ob = (size_t)n_pixels * 4;
+    int rc = chunk_reserve(ctx, fb + ob);
+    if (rc) return rc;
+    float *d = (float *)ctx->chunk_buf;
+    uint8_t *o = (uint8_t *)ctx->chunk_buf + fb;
+    HIP_TRY(hipMemcpyAsync(d, host_accum, fb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(pt::launch_resolve(d, n_pixels, spp, o, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(out_rgba, o, ob, hipMemcpyDeviceToHost));
     return HIPPT_OK;
 }
 

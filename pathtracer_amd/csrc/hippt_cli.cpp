@@ -6,6 +6,11 @@
 // Flags of the reference: --gpu (accepted; this binary has only the GPU path),
 // --quiet / -q. Extra flags default to reference behaviour:
 //   --scene PATH  --width W --height H --samples S  --seed N  --device D  --out PATH
+// Progressive / checkpointed rendering (analogue of the dispatch loop of src/gpu_renderer.rs:94-183):
+//   --chunk N          render N samples per pixel at a time, accumulating on the host
+//   --checkpoint PATH  after every chunk, save the accumulator + samples done to PATH
+//   --resume           start from PATH if it exists (same size and seed), render the remaining samples
+//   --preview          after every chunk, also write the image of the samples so far to the output path
 #include <sys/stat.h>
 
 #include <chrono>
@@ -26,7 +31,9 @@ int main(int argc, char **argv) {
     std::string scene_path = "scene.json", out_path;
     uint32_t w = 0, h = 0, spp = 0, seed = 0;
     int device = 0;
-    bool have_spp = false;
+    bool have_spp = false, resume = false, preview = false;
+    uint32_t chunk = 0;
+    std::string ckpt_path;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char * {
@@ -44,6 +51,10 @@ int main(int argc, char **argv) {
         else if (a == "--seed") seed = (uint32_t)std::strtoul(next(), nullptr, 10);
         else if (a == "--device") device = std::atoi(next());
         else if (a == "--out") out_path = next();
+        else if (a == "--chunk") chunk = (uint32_t)std::strtoul(next(), nullptr, 10);
+        else if (a == "--checkpoint") ckpt_path = next();
+        else if (a == "--resume") resume = true;
+        else if (a == "--preview") preview = true;
     }
 
     hippt_scene_file *sf = nullptr;
@@ -91,18 +102,6 @@ int main(int argc, char **argv) {
                     l.intensity[1], l.intensity[2]);
     }
 
-    std::printf("Running GPU renderer...\n");  // src/main.rs:90
-    std::vector<uint8_t> rgba((size_t)sc->width * sc->height * 4);
-    hippt_options opt{};
-    opt.seed = seed;
-    opt.device = device;
-    auto t0 = std::chrono::steady_clock::now();
-    if (hippt_render_rgba8(sc, &opt, rgba.data())) die("render");
-    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    double paths = (double)sc->width * sc->height * sc->samples;
-    std::printf("Rendered %ux%u at %u spp in %.3f s (%.1f Mpaths/s incl. device setup)\n", sc->width, sc->height,
-                sc->samples, secs, paths / secs / 1e6);
-
     char name[512];
     if (out_path.empty()) {
         hippt_render_image_name(sc->width, sc->height, sc->samples, c.aperture, c.focus, name, sizeof name);
@@ -110,6 +109,65 @@ int main(int argc, char **argv) {
     } else {
         std::snprintf(name, sizeof name, "%s", out_path.c_str());
     }
+
+    std::printf("Running GPU renderer...\n");  // src/main.rs:90
+    std::vector<uint8_t> rgba((size_t)sc->width * sc->height * 4);
+    hippt_options opt{};
+    opt.seed = seed;
+    opt.device = device;
+    auto t0 = std::chrono::steady_clock::now();
+    uint32_t rendered = sc->samples;
+    if (chunk == 0 && ckpt_path.empty()) {
+        if (hippt_render_rgba8(sc, &opt, rgba.data())) die("render");
+    } else {
+        if (sc->samples == 0) {
+            std::fprintf(stderr, "render.samples is 0\n");
+            return 101;
+        }
+        if (chunk == 0) chunk = sc->samples;
+        size_t npx = (size_t)sc->width * sc->height;
+        std::vector<float> accum(npx * 3, 0.0f);
+        uint32_t done = 0;
+        if (resume && !ckpt_path.empty()) {
+            FILE *probe = std::fopen(ckpt_path.c_str(), "rb");
+            if (probe) {
+                std::fclose(probe);
+                uint32_t ck_seed = 0;
+                if (hippt_checkpoint_load(ckpt_path.c_str(), accum.data(), sc->width, sc->height, &done, &ck_seed)) die("checkpoint");
+                if (ck_seed != seed || done > sc->samples) {
+                    std::fprintf(stderr, "checkpoint %s: seed %u / %u samples do not fit this render (seed %u, %u samples)\n",
+                                 ckpt_path.c_str(), ck_seed, done, seed, sc->samples);
+                    return 101;
+                }
+                std::printf("Resuming at sample %u of %u\n", done, sc->samples);
+            }
+        }
+        rendered = sc->samples - done;
+        hippt_context *ctx = nullptr;
+        if (hippt_create(device, &ctx)) die("device");
+        if (hippt_set_scene(ctx, sc)) die("scene");
+        while (done < sc->samples) {
+            uint32_t n = sc->samples - done < chunk ? sc->samples - done : chunk;  // the last chunk is short, not over-rendered
+            opt.sample_begin = done;
+            opt.sample_count = n;
+            if (hippt_render_accum_add_f32(ctx, &opt, accum.data())) die("render");
+            done += n;
+            if (!ckpt_path.empty() && hippt_checkpoint_save(ckpt_path.c_str(), accum.data(), sc->width, sc->height, done, seed))
+                die("checkpoint");
+            if (preview && done < sc->samples) {
+                if (hippt_resolve_f32(ctx, accum.data(), (uint32_t)npx, done, rgba.data())) die("resolve");
+                if (hippt_write_png_rgba8(name, rgba.data(), sc->width, sc->height)) die("save");
+            }
+            std::printf("  %u / %u samples\n", done, sc->samples);
+        }
+        if (hippt_resolve_f32(ctx, accum.data(), (uint32_t)npx, sc->samples, rgba.data())) die("resolve");
+        hippt_destroy(ctx);
+    }
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    double paths = (double)sc->width * sc->height * rendered;
+    std::printf("Rendered %ux%u at %u spp in %.3f s (%.1f Mpaths/s incl. device setup)\n", sc->width, sc->height,
+                rendered, secs, paths / secs / 1e6);
+
     if (hippt_write_png_rgba8(name, rgba.data(), sc->width, sc->height)) die("save");
     std::printf("Saved \xE2\x86\x92 %s\n", name);  // src/main.rs:106
     hippt_scene_free(sf);

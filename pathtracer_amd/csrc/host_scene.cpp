@@ -567,6 +567,54 @@ int hippt_render_image_name(uint32_t w, uint32_t h, uint32_t s, float ap, float 
     return std::snprintf(out, cap, "renders/render_%ux%u_s%u_ap%.2f_f%.1f_%s.png", w, h, s, (double)ap, (double)f, suf);
 }
 
+// Checkpoint of a progressive render (include/hippt.h): header + raw f32 sums.
+namespace {
+struct CkptHeader {
+    char magic[8];
+    uint32_t width, height, samples_done, seed, zero0, zero1;
+};
+static_assert(sizeof(CkptHeader) == 32, "checkpoint header is 32 bytes");
+}  // namespace
+
+int hippt_checkpoint_save(const char *path, const float *accum, uint32_t width, uint32_t height, uint32_t samples_done,
+                          uint32_t seed) {
+    if (!path || !accum || !width || !height) return hippt_set_error(HIPPT_ERR_INVALID, "bad checkpoint arguments");
+    std::string tmp = std::string(path) + ".tmp";
+    FILE *fp = std::fopen(tmp.c_str(), "wb");
+    if (!fp) return hippt_set_error(HIPPT_ERR_IO, "%s: %s", tmp.c_str(), std::strerror(errno));
+    CkptHeader h{{'H', 'I', 'P', 'P', 'T', 'A', 'C', '1'}, width, height, samples_done, seed, 0, 0};
+    size_t n = (size_t)width * height * 3;
+    bool ok = std::fwrite(&h, sizeof h, 1, fp) == 1 && std::fwrite(accum, sizeof(float), n, fp) == n;
+    ok = (std::fclose(fp) == 0) && ok;
+    if (!ok) {
+        std::remove(tmp.c_str());
+        return hippt_set_error(HIPPT_ERR_IO, "%s: short write", tmp.c_str());
+    }
+    if (std::rename(tmp.c_str(), path) != 0) return hippt_set_error(HIPPT_ERR_IO, "%s: %s", path, std::strerror(errno));
+    return HIPPT_OK;
+}
+
+int hippt_checkpoint_load(const char *path, float *accum, uint32_t width, uint32_t height, uint32_t *samples_done,
+                          uint32_t *seed) {
+    if (!path || !accum || !width || !height) return hippt_set_error(HIPPT_ERR_INVALID, "bad checkpoint arguments");
+    FILE *fp = std::fopen(path, "rb");
+    if (!fp) return hippt_set_error(HIPPT_ERR_IO, "%s: %s", path, std::strerror(errno));
+    CkptHeader h{};
+    size_t n = (size_t)width * height * 3;
+    int rc = HIPPT_OK;
+    if (std::fread(&h, sizeof h, 1, fp) != 1 || std::memcmp(h.magic, "HIPPTAC1", 8) != 0)
+        rc = hippt_set_error(HIPPT_ERR_INVALID, "%s: not a hippt checkpoint", path);
+    else if (h.width != width || h.height != height)
+        rc = hippt_set_error(HIPPT_ERR_INVALID, "%s: checkpoint is %ux%u, render is %ux%u", path, h.width, h.height, width, height);
+    else if (std::fread(accum, sizeof(float), n, fp) != n || std::fgetc(fp) != EOF)
+        rc = hippt_set_error(HIPPT_ERR_INVALID, "%s: size does not match %ux%u", path, width, height);
+    std::fclose(fp);
+    if (rc) return rc;
+    if (samples_done) *samples_done = h.samples_done;
+    if (seed) *seed = h.seed;
+    return HIPPT_OK;
+}
+
 // 8-bit RGBA, non-interlaced PNG: signature, IHDR, one IDAT (zlib), IEND.
 int hippt_write_png_rgba8(const char *path, const uint8_t *rgba, uint32_t w, uint32_t h) {
     if (!path || !rgba || !w || !h) return hippt_set_error(HIPPT_ERR_INVALID, "bad PNG arguments");

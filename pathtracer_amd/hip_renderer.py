@@ -88,6 +88,21 @@ class Context:
         _abi.check(self.lib.hippt_resolve_device(self.h, C.c_void_p(d_accum_ptr), spp, C.c_void_p(d_rgba_ptr),
                                                  C.c_void_p(stream)), self.lib)
 
+    def render_accum_add(self, host_accum, sample_begin, sample_count, seed=0, max_depth=0, flags=0):
+        """Progressive step (gpu_renderer.rs:94-183): renders a sample range and adds it to a HOST accumulator."""
+        assert host_accum.dtype == np.float32 and host_accum.flags["C_CONTIGUOUS"]
+        o = _opts(sample_begin, sample_count, max_depth, seed, flags, 0)
+        _abi.check(self.lib.hippt_render_accum_add_f32(self.h, C.byref(o), host_accum.ctypes.data_as(C.c_void_p)), self.lib)
+
+    def resolve(self, host_accum, spp):
+        """Average / ACES / gamma / u8 of a host accumulator [h, w, 3] -> uint8 [h, w, 4]."""
+        acc = np.ascontiguousarray(host_accum, np.float32)
+        n = acc.size // 3
+        out = np.empty(acc.shape[:-1] + (4,), np.uint8)
+        _abi.check(self.lib.hippt_resolve_f32(self.h, acc.ctypes.data_as(C.c_void_p), n, int(spp),
+                                              out.ctypes.data_as(C.c_void_p)), self.lib)
+        return out
+
     def read_counters(self):
         cn = (C.c_uint64 * _abi.N_COUNTERS)()
         _abi.check(self.lib.hippt_read_counters(self.h, cn), self.lib)
@@ -105,6 +120,24 @@ def render_image_name(w, h, s, ap, f):
     buf = C.create_string_buffer(256)
     lib.hippt_render_image_name(w, h, s, C.c_float(ap), C.c_float(f), buf, 256)
     return buf.value.decode()
+
+
+def checkpoint_save(path, accum, samples_done, seed=0):
+    """Accumulator [h, w, 3] + samples done -> checkpoint file (include/hippt.h)."""
+    lib = _abi.load_library()
+    acc = np.ascontiguousarray(accum, np.float32)
+    h, w = acc.shape[:2]
+    _abi.check(lib.hippt_checkpoint_save(str(path).encode(), acc.ctypes.data_as(C.c_void_p), w, h, int(samples_done), int(seed)), lib)
+
+
+def checkpoint_load(path, width, height):
+    """-> (accum [h, w, 3] float32, samples_done, seed)."""
+    lib = _abi.load_library()
+    acc = np.empty((height, width, 3), np.float32)
+    done, seed = C.c_uint32(), C.c_uint32()
+    _abi.check(lib.hippt_checkpoint_load(str(path).encode(), acc.ctypes.data_as(C.c_void_p), width, height,
+                                         C.byref(done), C.byref(seed)), lib)
+    return acc, done.value, seed.value
 
 
 def save_png(path, rgba):

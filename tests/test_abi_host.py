@@ -141,6 +141,33 @@ def test_png_writer_roundtrip(tmp_path):
     assert back.shape == (37, 53, 4) and np.array_equal(back, img)
 
 
+def test_checkpoint_roundtrip_and_rejections(tmp_path):
+    """Progressive accumulation: the host accumulator + samples done is the checkpoint."""
+    from pathtracer_amd import hip_renderer, _abi
+    rng = np.random.default_rng(0)
+    acc = rng.random((5, 7, 3), np.float32) * 1000
+    p = tmp_path / "job.acc"
+    hip_renderer.checkpoint_save(p, acc, 12345, seed=77)
+    assert p.stat().st_size == 32 + 5 * 7 * 3 * 4 and not (tmp_path / "job.acc.tmp").exists()
+    back, done, seed = hip_renderer.checkpoint_load(p, 7, 5)
+    assert np.array_equal(back, acc) and (done, seed) == (12345, 77)
+    raw = p.read_bytes()
+    assert raw[:8] == b"HIPPTAC1" and np.frombuffer(raw[8:24], "<u4").tolist() == [7, 5, 12345, 77]
+    with pytest.raises(_abi.HipptError, match="checkpoint is 7x5"):
+        hip_renderer.checkpoint_load(p, 5, 7)
+    (tmp_path / "short.acc").write_bytes(raw[:-4])
+    with pytest.raises(_abi.HipptError, match="size does not match"):
+        hip_renderer.checkpoint_load(tmp_path / "short.acc", 7, 5)
+    (tmp_path / "long.acc").write_bytes(raw + b"x")
+    with pytest.raises(_abi.HipptError, match="size does not match"):
+        hip_renderer.checkpoint_load(tmp_path / "long.acc", 7, 5)
+    (tmp_path / "bad.acc").write_bytes(b"NOTACKPT" + raw[8:])
+    with pytest.raises(_abi.HipptError, match="not a hippt checkpoint"):
+        hip_renderer.checkpoint_load(tmp_path / "bad.acc", 7, 5)
+    with pytest.raises(_abi.HipptError):
+        hip_renderer.checkpoint_load(tmp_path / "missing.acc", 7, 5)
+
+
 def test_invalid_tables_are_rejected_before_any_launch():
     from pathtracer_amd import HipptError, Scene, hip_renderer
     s = Scene.parse(json.dumps(MINI))

@@ -41,3 +41,60 @@ def test_cli_missing_scene_fails_like_expect(tmp_path):
     exe = os.path.join(ROOT, "pathtracer_amd", "bin", "hippt")
     r = subprocess.run([exe, "--gpu"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
     assert r.returncode == 101 and "scene file" in r.stderr      # scene.rs:95 expect("scene file") -> panic exit code 101
+
+
+def test_cli_progressive_checkpoint_and_resume(tmp_path):
+    """chunked rendering with host accumulation, checkpoint after every chunk, resume.
+    10 spp in chunks of 4 (the last chunk is short, not over-rendered as gpu_renderer.rs:98-102 does)."""
+    from PIL import Image
+    from pathtracer_amd import Scene, hip_renderer
+    exe = os.path.join(ROOT, "pathtracer_amd", "bin", "hippt")
+    scene = os.path.join(ROOT, "scenes", "scene.example.json")
+    base = [exe, "--gpu", "-q", "--scene", scene, "--width", "64", "--height", "48", "--seed", "3"]
+    ck = str(tmp_path / "job.acc")
+    r = subprocess.run(base + ["--samples", "10", "--chunk", "4", "--checkpoint", ck, "--preview", "--out", str(tmp_path / "a.png")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "4 / 10 samples" in r.stdout and "8 / 10 samples" in r.stdout and "10 / 10 samples" in r.stdout
+    acc, done, seed = hip_renderer.checkpoint_load(ck, 64, 48)
+    assert (done, seed) == (10, 3)
+    s = Scene.load(scene, 64, 48, 10)
+    one_shot = hip_renderer.render_accum(s, seed=3)
+    assert np.allclose(acc, one_shot, rtol=2e-6, atol=1e-6)        # equal up to f32 summation order
+    a = np.asarray(Image.open(tmp_path / "a.png"))
+    ref = hip_renderer.render(s, seed=3)
+    assert np.abs(a.astype(int) - ref.astype(int)).max() <= 1 and (a == ref).mean() > 0.999
+
+    # interrupted job: 6 samples now, the remaining 4 after --resume
+    ck2 = str(tmp_path / "job2.acc")
+    r = subprocess.run(base + ["--samples", "6", "--chunk", "4", "--checkpoint", ck2, "--out", str(tmp_path / "b6.png")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert hip_renderer.checkpoint_load(ck2, 64, 48)[1] == 6
+    r = subprocess.run(base + ["--samples", "10", "--chunk", "4", "--checkpoint", ck2, "--resume", "--out", str(tmp_path / "b.png")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "Resuming at sample 6 of 10" in r.stdout
+    acc2, done2, _ = hip_renderer.checkpoint_load(ck2, 64, 48)
+    assert done2 == 10 and np.allclose(acc2, one_shot, rtol=2e-6, atol=1e-6)
+    b = np.asarray(Image.open(tmp_path / "b.png"))
+    assert np.abs(b.astype(int) - ref.astype(int)).max() <= 1
+    # a checkpoint from another seed is refused
+    r = subprocess.run(base[:-1] + ["4", "--samples", "12", "--checkpoint", ck2, "--resume", "--out", str(tmp_path / "c.png")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 101 and "do not fit this render" in r.stderr
+
+
+def test_context_progressive_api_matches_one_shot():
+    from pathtracer_amd import Scene, hip_renderer
+    s = Scene.load(os.path.join(ROOT, "scenes", "glass_fog.json"), 50, 30, 9)
+    ctx = hip_renderer.Context(0)
+    ctx.set_scene(s)
+    acc = np.zeros((30, 50, 3), np.float32)
+    for b, c in ((0, 2), (2, 5), (7, 2)):
+        ctx.render_accum_add(acc, b, c, seed=8)
+    one = hip_renderer.render_accum(s, seed=8)
+    assert np.allclose(acc, one, rtol=2e-6, atol=1e-6)
+    img = ctx.resolve(acc, 9)
+    ref = hip_renderer.render(s, seed=8)
+    assert img.shape == ref.shape and np.abs(img.astype(int) - ref.astype(int)).max() <= 1
