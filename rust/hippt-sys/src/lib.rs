@@ -33,4 +33,16 @@ extern "C" {
     pub fn hippt_render_rgba8(scene: *const hippt_scene, opts: *const hippt_options, out_rgba: *mut u8) -> c_int;
     pub fn hippt_render_accum_f32(scene: *const hippt_scene, opts: *const hippt_options, out_accum: *mut f32,
                                   counters: *mut u64) -> c_int;
+    // resident context + progressive accumulation (long jobs, checkpoints)
+    pub fn hippt_create(device: c_int, out_ctx: *mut *mut hippt_context) -> c_int;
+    pub fn hippt_destroy(ctx: *mut hippt_context) -> c_int;
+    pub fn hippt_set_scene(ctx: *mut hippt_context, scene: *const hippt_scene) -> c_int;
+    pub fn hippt_render_accum_add_f32(ctx: *mut hippt_context, opts: *const hippt_options, host_accum: *mut f32) -> c_int;
+    pub fn hippt_resolve_f32(ctx: *mut hippt_context, host_accum: *const f32, n_pixels: u32, spp: u32,
+                             out_rgba: *mut u8) -> c_int;
+    pub fn hippt_checkpoint_save(path: *const c_char, accum: *const f32, width: u32, height: u32,
+                                 samples_done: u32, seed: u32) -> c_int;
+    pub fn hippt_checkpoint_load(path: *const c_char, accum: *mut f32, width: u32, height: u32,
+                                 samples_done: *mut u32, seed: *mut u32) -> c_int;
 }
+#[repr(C)] pub struct hippt_context { _private: [u8; 0] }
