@@ -1,0 +1,106 @@
+"""Randomised scenes: HIP integrator and unit kernels vs the oracle on scenes the fixed fixtures do not
+cover — object counts around the loops' unroll factors (spheres x4, planes x2), 1-5 lights, many materials
+(metal, glass of several iors, media of several densities / anisotropies), objects interleaved in scene
+order, overlapping and touching geometry."""
+import numpy as np
+import pytest
+
+from helpers import unit_vectors
+
+pytestmark = pytest.mark.gpu
+
+
+def random_scene(seed, n_sph, n_pl, n_light, w=56, h=40, spp=12):
+    from pathtracer_amd import Scene
+    rng = np.random.default_rng(seed)
+    s = Scene()
+    s.width, s.height, s.samples = w, h, spp
+    n_mat = int(rng.integers(1, 9))
+    for _ in range(n_mat):
+        kind = rng.choice(["matte", "metal", "glossy", "glass", "fog"], p=[0.4, 0.2, 0.15, 0.15, 0.1])
+        rgb = tuple(rng.uniform(0.1, 0.95, 3))
+        if kind == "matte":
+            s.add_material(rgb, roughness=float(rng.uniform(0.3, 1.0)))
+        elif kind == "metal":
+            s.add_material(rgb, metallic=1.0, roughness=float(rng.uniform(0.05, 0.6)))
+        elif kind == "glossy":
+            s.add_material(rgb, metallic=float(rng.uniform(0.2, 0.8)), roughness=float(rng.uniform(0.1, 0.9)))
+        elif kind == "glass":
+            s.add_material(rgb, ior=float(rng.uniform(1.1, 2.5)), roughness=0.05)
+        else:
+            s.add_material(rgb, ior=float(rng.choice([1.0, 1.3])), volume_density=float(rng.uniform(0.05, 0.8)),
+                           volume_anisotropy=float(rng.uniform(-0.8, 0.8)))
+    kinds = ["s"] * n_sph + ["p"] * n_pl
+    rng.shuffle(kinds)  # interleaved scene order
+    for k in kinds:
+        m = int(rng.integers(0, n_mat))
+        if k == "s":
+            s.add_sphere(tuple(rng.uniform([-3, -1, 2], [3, 3, 9])), float(rng.uniform(0.2, 1.2)), m, in_focus=bool(rng.random() < 0.3))
+        else:
+            axis = int(rng.integers(0, 3))
+            p = rng.uniform([-3, -1.5, 1], [3, 3.5, 10])
+            u, v = np.zeros(3), np.zeros(3)
+            u[(axis + 1) % 3], v[(axis + 2) % 3] = rng.uniform(1, 5), rng.uniform(1, 5)
+            if rng.random() < 0.4:  # tilted
+                u += rng.normal(scale=0.3, size=3)
+                v += rng.normal(scale=0.3, size=3)
+            s.add_plane(tuple(p), tuple(u), tuple(v), m)
+    for _ in range(n_light):
+        s.add_light(tuple(rng.uniform([-3, 2, 0], [3, 5, 9])), tuple(rng.normal(size=3)), tuple(rng.normal(size=3)),
+                    tuple(rng.uniform(5, 40, 3)))
+    s.set_camera((float(rng.uniform(-1, 1)), float(rng.uniform(0, 2)), -3.0), (0, 0.5, 5), (0, 1, 0), 55.0,
+                 float(rng.choice([0.0, 0.03])))
+    return s
+
+
+CASES = [(0, 1, 0, 1), (1, 0, 1, 1), (2, 3, 1, 2), (3, 4, 2, 1), (4, 5, 3, 3), (5, 7, 5, 2), (6, 8, 4, 5),
+         (7, 9, 0, 1), (8, 0, 7, 2), (9, 13, 6, 4), (10, 31, 9, 2), (11, 63, 11, 1)]
+
+
+@pytest.mark.parametrize("seed,n_sph,n_pl,n_light", CASES)
+def test_random_scene_render_and_hits(oracle, hip, seed, n_sph, n_pl, n_light):
+    from pathtracer_amd import hip_renderer
+    s = random_scene(seed, n_sph, n_pl, n_light)
+    # closest hit on random rays: bit-identical hit records where the same object wins
+    rng = np.random.default_rng(100 + seed)
+    n = 4096
+    ro = np.stack([rng.uniform(-3, 3, n), rng.uniform(-1, 3, n), rng.uniform(-3, 9, n)], 1).astype(np.float32)
+    rd = unit_vectors(rng, n)
+    t_h, n_h, i_h = hip.intersect(s, ro, rd)
+    t_o, n_o, i_o = oracle.unit.intersect(s, ro, rd)
+    same = i_h == i_o
+    assert same.mean() > 0.998, same.mean()
+    hit = same & (i_o >= 0)
+    if hit.any():
+        assert (t_h[hit] == t_o[hit]).mean() > 0.995
+        assert np.allclose(t_h[hit], t_o[hit], rtol=1e-5)
+        assert np.allclose(n_h[hit], n_o[hit], atol=1e-5)
+    occ_h = hip.occluded(s, ro, rd, rng.uniform(0.01, 80.0, n).astype(np.float32))
+    # (fresh dist2 for the oracle must be the same array: regenerate deterministically)
+    rng2 = np.random.default_rng(100 + seed)
+    rng2.uniform(-3, 3, n), rng2.uniform(-1, 3, n), rng2.uniform(-3, 9, n), unit_vectors(rng2, n)
+    d2 = rng2.uniform(0.01, 80.0, n).astype(np.float32)
+    assert (occ_h == oracle.unit.occluded(s, ro, rd, d2)).mean() > 0.999
+
+    # whole integrator, same RNG streams, event counters included
+    acc_h, cn_h = hip_renderer.render_accum(s, seed=seed, counters=True)
+    acc_o, cn_o = oracle.render_accum(s, seed=seed, counters=True)
+    assert np.isfinite(acc_h).all()
+    for k in ("paths", "extend_rays", "extend_hits", "shadow_rays", "nee_vertices", "glass_vertices",
+              "medium_vertices", "scatter_events", "diffuse_lobes", "spec_lobes"):
+        assert abs(cn_h[k] - cn_o[k]) <= 1e-2 * cn_o[k] + 12, (k, cn_h[k], cn_o[k])
+    err = np.abs(acc_h.astype(np.float64) - acc_o).max(axis=2)
+    scale = np.maximum(np.abs(acc_o).max(axis=2), 1e-3 * s.samples)
+    r = err / scale
+    # most pixels to rounding; flipped branches (grazing hits, u < R at glass, roulette, free-flight vs
+    # surface) change single samples in a minority of pixels
+    assert np.quantile(r, 0.5) < 1e-5, np.quantile(r, [0.5, 0.8, 0.95])
+    assert np.quantile(r, 0.8) < 1e-3, np.quantile(r, [0.5, 0.8, 0.95])
+    tot_h, tot_o = acc_h.sum(dtype=np.float64), acc_o.sum(dtype=np.float64)
+    assert abs(tot_h - tot_o) <= 2e-2 * abs(tot_o) + 1e-6, (tot_h, tot_o)
+    # wavefront variant renders the same image as the megakernel
+    if n_sph < 64:
+        from pathtracer_amd import _abi
+        acc_w = hip_renderer.render_accum(s, seed=seed, flags=_abi.FLAG_WAVEFRONT)
+        rw = np.abs(acc_w.astype(np.float64) - acc_h).max(axis=2) / np.maximum(np.abs(acc_h).max(axis=2), 1e-3 * s.samples)
+        assert np.quantile(rw, 0.9) < 1e-4, np.quantile(rw, [0.5, 0.9, 0.99])
