@@ -22,19 +22,37 @@ __device__ __forceinline__ void lane_pixel(const Params &P, uint32_t &x, uint32_
     y = ty * 16u + (wave >> 1) * 8u + (lane >> 3);
 }
 
+// Per-wave scratch in LDS: the 64 pixels' radiance sums and their RNG pixel keys.
+struct WaveLds {
+    float acc[64 * 3];
+    uint32_t mix[64];
+};
+
+// One wave renders the sample_count samples of its 8x8 pixels as a POOL of 64 * sample_count work items
+// (item i = sample i / 64 of pixel i % 64): a lane whose path has ended takes the next item, whichever
+// pixel it belongs to, so no lane idles while a neighbour with longer paths (a pixel on a sphere's rim, in
+// fog, next to the sky) finishes its samples. Every path is a function of (pixel, global sample index)
+// only, and a finished path's radiance is added to its pixel's sum in LDS, so the image is the same as
+// with one lane per pixel up to the order of the f32 additions (which is fixed: the item order and the LDS
+// atomics of a wave are deterministic).
 template <class Tbl, bool COUNT, bool BVH = false>
-__device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x, uint32_t y, bool in_image,
+__device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x_own, uint32_t y_own, bool in_image,
                                             float *__restrict__ accum, unsigned long long *__restrict__ counters,
-                                            Bvh bvh = Bvh{}, uint32_t *stack = nullptr) {
+                                            WaveLds *wl, Bvh bvh = Bvh{}, uint32_t *stack = nullptr) {
     Tracer<Tbl, COUNT, BVH> tr(P, tbl, bvh, stack);
-    const uint32_t pixel = y * P.width + x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t pixel = y_own * P.width + x_own;
     const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
-    const uint32_t pix_mixed = mix32(pixel + seed_mixed);
+    const uint32_t wx0 = x_own - (lane & 7u), wy0 = y_own - (lane >> 3);  // this wave's 8x8 tile
+    wl->mix[lane] = mix32(pixel + seed_mixed);
+    wl->acc[lane * 3 + 0] = 0.0f;
+    wl->acc[lane * 3 + 1] = 0.0f;
+    wl->acc[lane * 3 + 2] = 0.0f;
+    __builtin_amdgcn_wave_barrier();
 
-    uint32_t s = P.sample_begin;
-    const uint32_t s_end = in_image ? P.sample_begin + P.sample_count : P.sample_begin;
-
-    F3 sum = F3{0.0f, 0.0f, 0.0f};
+    uint32_t cur_lane = 0, cur_sample = 0;  // wave-uniform cursor into the item sequence
+    uint32_t my_pl = lane;                  // pixel (0..63 within the tile) of this lane's current path
+    F3 psum = F3{0.0f, 0.0f, 0.0f};         // radiance of the current path
     // path state
     Rng rng{0u, 1u};
     F3 ro = F3{0, 0, 0}, rd = F3{0, 0, 1}, T = F3{1, 1, 1};
@@ -42,20 +60,35 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
     int media = -1;  // material id of the current medium, -1 = none
     bool alive = false;
 
+    if (__any(in_image))
     for (;;) {
-        if (!alive) {
-            if (s >= s_end) break;
-            // renderer.rs:170-178: new camera path
-            rng.seed(seed_mixed, pix_mixed, s);
-            float jx = rng.gen(), jy = rng.gen(), ds = rng.gen(), dt = rng.gen();
-            camera_ray(P, x, y, jx, jy, ds, dt, ro, rd);
-            T = F3{1, 1, 1};
-            depth = 0;
-            media = -1;
-            alive = true;
-            ++s;
-            tr.bump(HIPPT_C_PATHS);
+        const unsigned long long need = __ballot(!alive);
+        if (need != 0ull) {
+            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            uint32_t pos = cur_lane + rank;
+            uint32_t tot = cur_lane + (uint32_t)__popcll(need);
+            uint32_t my_sample = cur_sample + (pos >> 6);
+            cur_sample += tot >> 6;
+            cur_lane = tot & 63u;
+            if (!alive) {
+                if (my_sample >= P.sample_count) break;  // pool exhausted: this lane is finished
+                my_pl = pos & 63u;
+                uint32_t px = wx0 + (my_pl & 7u), py = wy0 + (my_pl >> 3);
+                if ((px < P.width) & (py < P.height)) {
+                    // renderer.rs:170-178: new camera path
+                    rng.seed(seed_mixed, wl->mix[my_pl], P.sample_begin + my_sample);
+                    float jx = rng.gen(), jy = rng.gen(), ds = rng.gen(), dt = rng.gen();
+                    camera_ray(P, px, py, jx, jy, ds, dt, ro, rd);
+                    T = F3{1, 1, 1};
+                    psum = F3{0.0f, 0.0f, 0.0f};
+                    depth = 0;
+                    media = -1;
+                    alive = true;
+                    tr.bump(HIPPT_C_PATHS);
+                }
+            }
         }
+        if (!alive) continue;  // the item's pixel lies outside the image (ragged edge tiles only)
 
         // ---- one vertex of renderer.rs:237-353 ----
         RayK ray = make_ray(ro, rd);
@@ -111,7 +144,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
         if (kind != 0) {
             ShadeK sk = make_shade(n, -rd, m);
             F3 D = tr.direct_light(x, sk, rng);
-            sum = sum + T * D;  // :181 + :285 / :325, added straight into the pixel sum
+            psum = psum + T * D;  // :285 / :325
             if (kind == 2) {
                 float ct = sample_phase_function(m.aniso, rng.gen());
                 float up = rng.gen();
@@ -150,14 +183,20 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
             }
         }
         ++depth;
-        if (done || depth >= P.max_depth) alive = false;  // :246
+        if (done || depth >= P.max_depth) {  // :246; the path's radiance goes to its pixel's sum (:181)
+            alive = false;
+            __hip_atomic_fetch_add(&wl->acc[my_pl * 3 + 0], psum.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&wl->acc[my_pl * 3 + 1], psum.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&wl->acc[my_pl * 3 + 2], psum.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
 
+    __builtin_amdgcn_wave_barrier();
     if (in_image) {
         float *px = accum + (size_t)pixel * 3;
-        px[0] += sum.x;
-        px[1] += sum.y;
-        px[2] += sum.z;
+        px[0] += wl->acc[lane * 3 + 0];
+        px[1] += wl->acc[lane * 3 + 1];
+        px[2] += wl->acc[lane * 3 + 2];
     }
     if (COUNT) {
         // wave-reduce then one atomic per wave and counter
@@ -183,7 +222,8 @@ __global__ __launch_bounds__(256, PT_MIN_WAVES) void pt_megakernel_lds(Params P,
     uint32_t x, y;
     lane_pixel(P, x, y);
     bool in_image = (x < P.width) & (y < P.height);
-    trace_pixel<TblLds, COUNT>(P, TblLds{s_tbl}, x, y, in_image, accum, counters);
+    __shared__ WaveLds s_wl[4];
+    trace_pixel<TblLds, COUNT>(P, TblLds{s_tbl}, x, y, in_image, accum, counters, &s_wl[threadIdx.x >> 6]);
 }
 
 // Scene tables read from global memory (scenes too large for LDS).
@@ -194,7 +234,8 @@ __global__ __launch_bounds__(256) void pt_megakernel_global(Params P, const floa
     uint32_t x, y;
     lane_pixel(P, x, y);
     bool in_image = (x < P.width) & (y < P.height);
-    trace_pixel<TblGlobal, COUNT>(P, TblGlobal{blob}, x, y, in_image, accum, counters);
+    __shared__ WaveLds s_wl[4];
+    trace_pixel<TblGlobal, COUNT>(P, TblGlobal{blob}, x, y, in_image, accum, counters, &s_wl[threadIdx.x >> 6]);
 }
 
 // Many-sphere scenes: spheres through the LBVH, everything else from global tables.
@@ -206,7 +247,9 @@ __global__ __launch_bounds__(256) void pt_megakernel_bvh(Params P, const float4 
     uint32_t x, y;
     lane_pixel(P, x, y);
     bool in_image = (x < P.width) & (y < P.height);
-    trace_pixel<TblGlobal, COUNT, true>(P, TblGlobal{blob}, x, y, in_image, accum, counters, bvh, s_stack + threadIdx.x);
+    __shared__ WaveLds s_wl[4];
+    trace_pixel<TblGlobal, COUNT, true>(P, TblGlobal{blob}, x, y, in_image, accum, counters, &s_wl[threadIdx.x >> 6], bvh,
+                                        s_stack + threadIdx.x);
 }
 
 // renderer.rs:184-191
