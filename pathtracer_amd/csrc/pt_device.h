@@ -290,8 +290,9 @@ __device__ __forceinline__ void finish_hit(const Tbl &tbl, const Params &P, cons
 }
 
 // renderer.rs:44-46 for NS shadow rays that leave the same point x: origin x + l*eps, unit
-// direction l[s], occluded iff some object has t > 0 (plane: t > 1e-4) and t*t < lim[s]
-// (= dist2*0.999). Every object is tested, branch-free (on scene.example the reference's
+// direction l[s], occluded iff some object has t > 0 (plane: t > 1e-4) and t*t < dist2*0.999,
+// i.e. t < tmax[s] = sqrt(0.999 dist2); both bounds are checked with one compare, |t - mid| < half
+// (compares issue at half rate on gfx950). Every object is tested, branch-free (on scene.example the reference's
 // first-occluder early out skips only 8 % of the tests, and a per-lane exit costs more in
 // divergence than it saves). The loops are object-major so that each table row is read once
 // per NS rays and the terms that depend only on (x, object) are formed once:
@@ -303,7 +304,7 @@ __device__ __forceinline__ void finish_hit(const Tbl &tbl, const Params &P, cons
 // ~1e-7 relative in t; they can only move an occlusion decision that sits on its threshold).
 template <class Tbl, int NS, bool COUNT>
 __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, F3 x, float eps, const F3 (&l)[NS],
-                                               const float (&lim)[NS], bool (&occ)[NS], uint32_t &n_sph_tests,
+                                               const float (&tmax)[NS], bool (&occ)[NS], uint32_t &n_sph_tests,
                                                uint32_t &n_pl_tests, bool spheres = true) {
     const uint32_t n_sph = spheres ? P.n_sph : 0u;  // false: the caller has tested the spheres (BVH) and set occ[]
     if (spheres) {
@@ -311,6 +312,9 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
         for (int s = 0; s < NS; ++s) occ[s] = false;
     }
     const float eps2 = eps * eps, two_eps = 2.0f * eps;
+    float half[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) half[s] = 0.5f * tmax[s];
 #pragma unroll 1
     for (uint32_t i = 0; i < n_sph; ++i) {
         float4 c = tbl.ld(P.sph_off + i);
@@ -322,7 +326,7 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
             float h = d1 + eps;
             float cs = fmaf(two_eps, d1, K);
             float t = -h - fsqrt(fmaf(h, h, -cs));
-            occ[s] = occ[s] | ((t > 0.0f) & (t * t < lim[s]));
+            occ[s] = occ[s] | (fabsf(t - half[s]) < half[s]);  // 0 < t < tmax (NaN: false)
         }
     }
     if (COUNT) n_sph_tests += NS * n_sph;
@@ -337,11 +341,12 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
         for (int s = 0; s < NS; ++s) {
             float denom = dot(n, l[s]);
             float tp = Dn * rcp(denom);
-            float t = tp - eps;
             float du = fmaf(tp, dot(l[s], u), Du);
             float dv = fmaf(tp, dot(l[s], v), Dv);
-            bool ok = (fabsf(denom) >= 1e-6f) & (t > 1e-4f) & (fmaxf(fabsf(du), fabsf(dv)) <= 1.0f);
-            occ[s] = occ[s] | (ok & (t * t < lim[s]));
+            // 1e-4 < t < tmax with t = tp - eps:  |t - (half + 5e-5)| < half - 5e-5
+            float dt = (tp - (eps + 5e-5f)) - half[s];
+            bool ok = (fabsf(denom) >= 1e-6f) & (fmaxf(fabsf(du), fabsf(dv)) <= 1.0f);
+            occ[s] = occ[s] | (ok & (fabsf(dt) < half[s] - 5e-5f));
         }
     }
     if (COUNT) n_pl_tests += NS * P.n_pl;

@@ -331,7 +331,7 @@ __global__ void pt_unit_occluded(Params P, const float4 *__restrict__ blob, uint
     TblLds tbl{s_tbl};
     // production shadow routine with the origin offset folded out (eps = 0); rd must be unit length
     F3 l[1] = {ld3(rd, i)};
-    float lim[1] = {dist2[i] * 0.999f};
+    float lim[1] = {fsqrt(dist2[i] * 0.999f)};
     bool occ[1];
     uint32_t a = 0, b = 0;
     occluded_multi<TblLds, 1, false>(tbl, P, ld3(ro, i), 0.0f, l, lim, occ, a, b);

@@ -63,7 +63,7 @@ struct Tracer {
             F3 contrib = F3{0.0f, 0.0f, 0.0f};
             // the light's 4 shadow samples (:35-47) are drawn first, then tested together
             F3 l[4];
-            float lim[4];  // dist2 * 0.999 (:46)
+            float d2[4], tmax[4];  // dist2; sqrt(dist2 * 0.999) (:46)
             bool occ[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -72,25 +72,27 @@ struct Tracer {
                 F3 lp = f3(l0) + f3(l1) * e1 + f3(l2) * e2;
                 F3 lvec = lp - x;
                 float dist2 = dot(lvec, lvec);
-                l[s] = lvec * rsq(dist2);
-                lim[s] = dist2 * 0.999f;
+                float inv = rsq(dist2);
+                l[s] = lvec * inv;
+                d2[s] = dist2;
+                tmax[s] = (dist2 * inv) * 0.99949987493746f;  // |lvec| sqrt(0.999)
             }
             bump(HIPPT_C_SHADOW_RAYS, 4);
             if constexpr (BVH) {
 #pragma unroll 1
                 for (int s = 0; s < 4; ++s) {
                     uint32_t nt = 0;
-                    occ[s] = bvh_any(bvh, make_ray(madd(x, l[s], 1e-4f), l[s]), lim[s], stack, 256u, nt);
+                    occ[s] = bvh_any(bvh, make_ray(madd(x, l[s], 1e-4f), l[s]), d2[s] * 0.999f, stack, 256u, nt);
                     bump(HIPPT_C_SHADOW_SPHERE_TESTS, nt);
                 }
             }
-            occluded_multi<Tbl, 4, COUNT>(tbl, P, x, 1e-4f, l, lim, occ, cnt[HIPPT_C_SHADOW_SPHERE_TESTS],
+            occluded_multi<Tbl, 4, COUNT>(tbl, P, x, 1e-4f, l, tmax, occ, cnt[HIPPT_C_SHADOW_SPHERE_TESTS],
                                           cnt[HIPPT_C_SHADOW_PLANE_TESTS], !BVH);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (!occ[s]) {
                     bool lit;
-                    F3 c = nee_eval(sk, l[s], lim[s] * (1.0f / 0.999f), f3(l4), l0.w, f3(l3), lit);
+                    F3 c = nee_eval(sk, l[s], d2[s], f3(l4), l0.w, f3(l3), lit);
                     if (lit) bump(HIPPT_C_LIT_EVALS);
                     contrib = contrib + c;
                 }
