@@ -102,7 +102,7 @@ struct Rng {
     __device__ __forceinline__ float gen() {
         uint32_t r = s0 + s1;
         uint32_t t = s1 ^ s0;
-        s0 = __builtin_rotateleft32(s0, 26) ^ t ^ (t << 9);
+        s0 = __builtin_amdgcn_bitop3_b32(__builtin_rotateleft32(s0, 26), t, t << 9, 0x96);  // a ^ b ^ c in one v_bitop3_b32
         s1 = __builtin_rotateleft32(t, 13);
         return (float)(r >> 8) * 5.9604644775390625e-08f;  // 2^-24: rand's Standard f32, [0,1)
     }
@@ -302,6 +302,14 @@ __device__ __forceinline__ void finish_hit(const Tbl &tbl, const Params &P, cons
 //           hit - p = (x - p) + l (t + eps)            =>  d.u' = Du + (t + eps) l.u'
 // which is the arithmetic of sphere.rs:26-33 / plane.rs:25-52 re-associated (differences
 // ~1e-7 relative in t; they can only move an occlusion decision that sits on its threshold).
+// a - b that is never contracted into an FMA with the product that formed a: with a literal b the
+// subtraction is a full-rate VOP2, while the fused form needs the constant in an SGPR, and VALU
+// instructions with an SGPR source issue at half rate on gfx950.
+__device__ __forceinline__ float sub_unfused(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+
 template <class Tbl, int NS, bool COUNT>
 __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, F3 x, float eps, const F3 (&l)[NS],
                                                const float (&tmax)[NS], bool (&occ)[NS], uint32_t &n_sph_tests,
@@ -344,7 +352,7 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
             float du = fmaf(tp, dot(l[s], u), Du);
             float dv = fmaf(tp, dot(l[s], v), Dv);
             // 1e-4 < t < tmax with t = tp - eps:  |t - (half + 5e-5)| < half - 5e-5
-            float dt = (tp - (eps + 5e-5f)) - half[s];
+            float dt = sub_unfused(tp, eps + 5e-5f) - half[s];
             bool ok = (fabsf(denom) >= 1e-6f) & (fmaxf(fabsf(du), fabsf(dv)) <= 1.0f);
             occ[s] = occ[s] | (ok & (fabsf(dt) < half[s] - 5e-5f));
         }
@@ -479,8 +487,9 @@ __device__ __forceinline__ ShadeK make_shade(F3 n, F3 v, const Mat &m) {
 // BRDF branch (:55) was reached.
 __device__ __forceinline__ F3 nee_eval(const ShadeK &s, F3 l, float dist2, F3 light_n, float light_area,
                                        F3 intensity, bool &lit) {
-    float n_dot_l = fmaxf(dot(s.n, l), 0.0f);
-    float cos_l = fmaxf(-dot(l, light_n), 0.0f);
+    // .max(0.0) of renderer.rs:49,53 is implied by the two `> 0` tests that follow it (:50,:55)
+    float n_dot_l = dot(s.n, l);
+    float cos_l = -dot(l, light_n);
     lit = (n_dot_l > 0.0f) & (cos_l > 0.0f);
     if (!lit) return F3{0.0f, 0.0f, 0.0f};
     float falloff = cos_l * rcp(dist2);
