@@ -289,19 +289,6 @@ __device__ __forceinline__ void finish_hit(const Tbl &tbl, const Params &P, cons
     });
 }
 
-// renderer.rs:44-46 for NS shadow rays that leave the same point x: origin x + l*eps, unit
-// direction l[s], occluded iff some object has t > 0 (plane: t > 1e-4) and t*t < dist2*0.999,
-// i.e. t < tmax[s] = sqrt(0.999 dist2); both bounds are checked with one compare, |t - mid| < half
-// (compares issue at half rate on gfx950, DESIGN.md §3). Every object is tested, branch-free (on scene.example the reference's
-// first-occluder early out skips only 8 % of the tests, and a per-lane exit costs more in
-// divergence than it saves). The loops are object-major so that each table row is read once
-// per NS rays and the terms that depend only on (x, object) are formed once:
-//   sphere: oc = X + eps l, X = x - c  =>  h = oc.l = X.l + eps        (l.l = 1 to rounding)
-//           oc.oc - r^2 = K + 2 eps X.l + eps^2, K = X.X - r^2
-//   plane : (p - o).n = Dn - eps n.l, Dn = (p - x).n  =>  t = Dn/(n.l) - eps
-//           hit - p = (x - p) + l (t + eps)            =>  d.u' = Du + (t + eps) l.u'
-// which is the arithmetic of sphere.rs:26-33 / plane.rs:25-52 re-associated (differences
-// ~1e-7 relative in t; they can only move an occlusion decision that sits on its threshold).
 // a - b that is never contracted into an FMA with the product that formed a: with a literal b the
 // subtraction is a full-rate VOP2, while the fused form needs the constant in an SGPR, and VALU
 // instructions with an SGPR source issue at half rate on gfx950.
@@ -310,6 +297,19 @@ __device__ __forceinline__ float sub_unfused(float a, float b) {
     return a - b;
 }
 
+// renderer.rs:44-46 for NS shadow rays that leave the same point x: origin x + l*eps, unit
+// direction l[s], occluded iff some object has t > 0 (plane: t > 1e-4) and t*t < dist2*0.999,
+// i.e. t < tmax[s] = sqrt(0.999 dist2); both bounds are checked with one compare, |t - mid| < half
+// (compares issue at half rate on gfx950, DESIGN.md §3). Every object is tested, branch-free (on scene.example the reference's
+// first-occluder early out skips only 8 % of the tests, and a per-lane exit costs more in
+// divergence than it saves). The loops are object-major so that each table row is read once
+// per NS rays and the terms that depend only on (x, object) are formed once:
+//   sphere: oc = X + eps l, X = x - c  =>  oc.l = X.l + eps             (l.l = 1 to rounding)
+//           (oc.l)^2 - (oc.oc - r^2) = (X.l)^2 - (X.X - r^2)         (the eps terms cancel)
+//   plane : (p - o).n = Dn - eps n.l, Dn = (p - x).n  =>  t = Dn/(n.l) - eps
+//           hit - p = (x - p) + l (t + eps)            =>  d.u' = Du + (t + eps) l.u'
+// which is the arithmetic of sphere.rs:26-33 / plane.rs:25-52 re-associated (differences
+// ~1e-7 relative in t; they can only move an occlusion decision that sits on its threshold).
 template <class Tbl, int NS, bool COUNT>
 __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, F3 x, float eps, const F3 (&l)[NS],
                                                const float (&tmax)[NS], bool (&occ)[NS], uint32_t &n_sph_tests,
@@ -319,22 +319,22 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
 #pragma unroll
         for (int s = 0; s < NS; ++s) occ[s] = false;
     }
-    const float eps2 = eps * eps, two_eps = 2.0f * eps;
-    float half[NS];
+    // q = eps + tmax/2: with t = t0 - eps (t0 measured from x), 0 < t < tmax  <=>  |t0 - q| < q - eps
+    float q[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) half[s] = 0.5f * tmax[s];
+    for (int s = 0; s < NS; ++s) q[s] = fmaf(0.5f, tmax[s], eps);
 #pragma unroll 1
     for (uint32_t i = 0; i < n_sph; ++i) {
         float4 c = tbl.ld(P.sph_off + i);
         F3 X = x - f3(c);
-        float K = fmaf(X.z, X.z, fmaf(X.y, X.y, fmaf(X.x, X.x, eps2 - c.w)));  // X.X - r^2 + eps^2
+        float C0 = fmaf(X.z, X.z, fmaf(X.y, X.y, fmaf(X.x, X.x, -c.w)));  // X.X - r^2
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
+            // the discriminant does not depend on where along the ray the origin sits: with o = x + eps l,
+            // (oc.l)^2 - (oc.oc - r^2) = (X.l)^2 - (X.X - r^2); the near root from x is t0 = -X.l - sqrt(disc)
             float d1 = dot(X, l[s]);
-            float h = d1 + eps;
-            float cs = fmaf(two_eps, d1, K);
-            float t = -h - fsqrt(fmaf(h, h, -cs));
-            occ[s] = occ[s] | (fabsf(t - half[s]) < half[s]);  // 0 < t < tmax (NaN: false)
+            float t0 = -d1 - fsqrt(fmaf(d1, d1, -C0));
+            occ[s] = occ[s] | (fabsf(t0 - q[s]) < q[s] - eps);  // NaN: false
         }
     }
     if (COUNT) n_sph_tests += NS * n_sph;
@@ -351,10 +351,10 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
             float tp = Dn * rcp(denom);
             float du = fmaf(tp, dot(l[s], u), Du);
             float dv = fmaf(tp, dot(l[s], v), Dv);
-            // 1e-4 < t < tmax with t = tp - eps:  |t - (half + 5e-5)| < half - 5e-5
-            float dt = sub_unfused(tp, eps + 5e-5f) - half[s];
+            // 1e-4 < t < tmax with t = tp - eps:  |tp - 5e-5 - q| < q - eps - 5e-5
+            float dt = sub_unfused(tp, 5e-5f) - q[s];
             bool ok = (fabsf(denom) >= 1e-6f) & (fmaxf(fabsf(du), fabsf(dv)) <= 1.0f);
-            occ[s] = occ[s] | (ok & (fabsf(dt) < half[s] - 5e-5f));
+            occ[s] = occ[s] | (ok & (fabsf(dt) < q[s] - (eps + 5e-5f)));
         }
     }
     if (COUNT) n_pl_tests += NS * P.n_pl;
