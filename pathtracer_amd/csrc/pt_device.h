@@ -465,9 +465,12 @@ __device__ __forceinline__ Mat load_mat(const Tbl &tbl, uint32_t mat_off, uint32
     return m;
 }
 
-struct ShadeK {  // per-vertex invariants of renderer.rs:59,63,72
+struct ShadeK {  // per-vertex invariants of renderer.rs:59,63,65-66,72
     F3 n, v, f0, diffuse_over_pi;
-    float n_dot_v, roughness;
+    float a2m1;     // a^2 - 1, a = roughness (un-squared, quirk Q7)
+    float k;        // a^2 / 2 (ggx.rs:14)
+    float four_nv;  // 4 n.v (:69)
+    float spec_v;   // a^2 n.v / (pi (n.v (1 - k) + k)): the n.v-only factors of D G
 };
 __device__ __forceinline__ ShadeK make_shade(F3 n, F3 v, const Mat &m) {
     ShadeK s;
@@ -477,29 +480,36 @@ __device__ __forceinline__ ShadeK make_shade(F3 n, F3 v, const Mat &m) {
     s.f0 = F3{fmaf(m.color.x, m.metallic, 0.04f * om), fmaf(m.color.y, m.metallic, 0.04f * om),
               fmaf(m.color.z, m.metallic, 0.04f * om)};
     s.diffuse_over_pi = m.color * (om * 0.31830988618379067154f);
-    s.n_dot_v = fmaxf(dot(n, v), 1e-4f);
-    s.roughness = m.roughness;
+    float nv = fmaxf(dot(n, v), 1e-4f);
+    float a2 = m.roughness * m.roughness;
+    s.a2m1 = a2 - 1.0f;
+    s.k = 0.5f * a2;
+    s.four_nv = 4.0f * nv;
+    s.spec_v = a2 * nv * rcp(3.14159265358979323846f * fmaf(nv, 1.0f - s.k, s.k));
     return s;
 }
 
 // renderer.rs:49-77: one visible light sample. Returns the contribution
 // (already multiplied by intensity * area * falloff); `lit` tells whether the
-// BRDF branch (:55) was reached.
-__device__ __forceinline__ F3 nee_eval(const ShadeK &s, F3 l, float dist2, F3 light_n, float light_area,
+// BRDF branch (:55) was reached. inv_dist2 = 1 / |lp - x|^2.
+// The specular term D G / (4 n.v n.l + 1e-6) (ggx.rs:10-18, renderer.rs:65-70) is formed over ONE common
+// denominator, q^2 (n.l (1 - k) + k) (4 n.v n.l + 1e-6), with the n.v-only factors hoisted into ShadeK:
+// one v_rcp_f32 per sample instead of four (transcendentals issue at quarter rate).
+__device__ __forceinline__ F3 nee_eval(const ShadeK &s, F3 l, float inv_dist2, F3 light_n, float light_area,
                                        F3 intensity, bool &lit) {
     // .max(0.0) of renderer.rs:49,53 is implied by the two `> 0` tests that follow it (:50,:55)
     float n_dot_l = dot(s.n, l);
     float cos_l = -dot(l, light_n);
     lit = (n_dot_l > 0.0f) & (cos_l > 0.0f);
     if (!lit) return F3{0.0f, 0.0f, 0.0f};
-    float falloff = cos_l * rcp(dist2);
+    float falloff = cos_l * inv_dist2;
     F3 h = normalize(s.v + l);
     float n_dot_h = fmaxf(dot(s.n, h), 0.0f);
     float v_dot_h = fmaxf(dot(s.v, h), 0.0f);
     F3 f = fresnel_schlick(v_dot_h, s.f0);
-    float d = d_term(n_dot_h, s.roughness);
-    float g = g_term(s.n_dot_v, n_dot_l, s.roughness);
-    float spec = d * g * rcp(fmaf(4.0f * s.n_dot_v, n_dot_l, 1e-6f));
+    float q = fmaf(n_dot_h * n_dot_h, s.a2m1, 1.0f);
+    float den = (q * q) * fmaf(n_dot_l, 1.0f - s.k, s.k) * fmaf(s.four_nv, n_dot_l, 1e-6f);
+    float spec = (s.spec_v * n_dot_l) * rcp(den);
     F3 kd = F3{1.0f - f.x, 1.0f - f.y, 1.0f - f.z};
     F3 brdf = s.diffuse_over_pi * kd + f * spec;
     float w = n_dot_l * (light_area * falloff);

@@ -355,7 +355,7 @@ __global__ void pt_unit_nee_eval(uint32_t n, const float *nrm, const float *v, c
     float area = fsqrt(dot(cr, cr));
     F3 ln = normalize(cr);
     bool lit;
-    F3 c = nee_eval(sk, ld3(l, i), dist2[i], ln, area, F3{light.intensity[0], light.intensity[1], light.intensity[2]},
+    F3 c = nee_eval(sk, ld3(l, i), rcp(dist2[i]), ln, area, F3{light.intensity[0], light.intensity[1], light.intensity[2]},
                     lit);
     st3(out, i, c);
 }

@@ -63,7 +63,7 @@ struct Tracer {
             F3 contrib = F3{0.0f, 0.0f, 0.0f};
             // the light's 4 shadow samples (:35-47) are drawn first, then tested together
             F3 l[4];
-            float d2[4], tmax[4];  // dist2; sqrt(dist2 * 0.999) (:46)
+            float id2[4], tmax[4];  // 1 / dist2; sqrt(dist2 * 0.999) (:46)
             bool occ[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -74,7 +74,7 @@ struct Tracer {
                 float dist2 = dot(lvec, lvec);
                 float inv = rsq(dist2);
                 l[s] = lvec * inv;
-                d2[s] = dist2;
+                id2[s] = inv * inv;
                 tmax[s] = (dist2 * inv) * 0.99949987493746f;  // |lvec| sqrt(0.999)
             }
             bump(HIPPT_C_SHADOW_RAYS, 4);
@@ -82,7 +82,7 @@ struct Tracer {
 #pragma unroll 1
                 for (int s = 0; s < 4; ++s) {
                     uint32_t nt = 0;
-                    occ[s] = bvh_any(bvh, make_ray(madd(x, l[s], 1e-4f), l[s]), d2[s] * 0.999f, stack, 256u, nt);
+                    occ[s] = bvh_any(bvh, make_ray(madd(x, l[s], 1e-4f), l[s]), tmax[s] * tmax[s], stack, 256u, nt);
                     bump(HIPPT_C_SHADOW_SPHERE_TESTS, nt);
                 }
             }
@@ -92,7 +92,7 @@ struct Tracer {
             for (int s = 0; s < 4; ++s) {
                 if (!occ[s]) {
                     bool lit;
-                    F3 c = nee_eval(sk, l[s], d2[s], f3(l4), l0.w, f3(l3), lit);
+                    F3 c = nee_eval(sk, l[s], id2[s], f3(l4), l0.w, f3(l3), lit);
                     if (lit) bump(HIPPT_C_LIT_EVALS);
                     contrib = contrib + c;
                 }
