@@ -65,7 +65,8 @@ class Options(C.Structure):
 
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "lib", "libhippt.so")
+# HIPPT_LIB: another build of the same library (A/B timing of kernel variants with tools/ab_bench.sh)
+LIB_PATH = os.environ.get("HIPPT_LIB") or os.path.join(_PKG_DIR, "lib", "libhippt.so")
 
 # every symbol include/hippt.h declares
 EXPORTED_SYMBOLS = (
