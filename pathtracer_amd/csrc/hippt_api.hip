@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -165,6 +166,7 @@ int build_bvh(const float4 *d_blob, const pt::Params &P, pt::BvhBuffers &out, hi
         pt::bvh_free(out);
         return hippt_set_error(HIPPT_ERR_DEVICE, "LBVH build failed: %s", hipGetErrorString(e));
     }
+    if (std::getenv("HIPPT_DEBUG")) std::fprintf(stderr, "[hippt] LBVH over %u spheres: depth %d\n", P.n_sph, *depth);
     if (*depth > pt::BVH_STACK) {
         pt::bvh_free(out);
         return hippt_set_error(HIPPT_ERR_LIMIT, "LBVH depth %d exceeds the traversal stack (%d)", *depth, pt::BVH_STACK);
@@ -323,7 +325,8 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
         if (wavefront)
             HIP_TRY(pt::wavefront_render(P, ctx->d_blob, d_accum, ctx->wf_ws, st, nullptr));
         else if (use_bvh)
-            HIP_TRY(pt::launch_megakernel_bvh(P, ctx->d_blob, bvh_view(ctx->bvh), d_accum, ctx->d_counters, count, st));
+            HIP_TRY(pt::launch_megakernel_bvh(P, ctx->d_blob, bvh_view(ctx->bvh), (uint32_t)std::min(pt::BVH_STACK, std::max(8, ctx->bvh_depth + 2)),
+                                              d_accum, ctx->d_counters, count, st));
         else
             HIP_TRY(pt::launch_megakernel(P, ctx->d_blob, d_accum, ctx->d_counters, count, lds, st));
         HIP_TRY(hipEventRecord(ev.second, st));

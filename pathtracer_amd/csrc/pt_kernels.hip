@@ -243,7 +243,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(256) void pt_megakernel_bvh(Params P, const float4 *__restrict__ blob, Bvh bvh,
                                                          float *__restrict__ accum,
                                                          unsigned long long *__restrict__ counters) {
-    __shared__ uint32_t s_stack[BVH_STACK * 256];
+    extern __shared__ uint32_t s_stack[];  // stack_entries x 256 (launch_megakernel_bvh sizes it from the tree depth)
     uint32_t x, y;
     lane_pixel(P, x, y);
     bool in_image = (x < P.width) & (y < P.height);
@@ -450,14 +450,15 @@ hipError_t launch_megakernel(const Params &P, const float4 *blob, float *accum, 
     return hipGetLastError();
 }
 
-hipError_t launch_megakernel_bvh(const Params &P, const float4 *blob, const Bvh &bvh, float *accum,
+// stack_entries: per-lane traversal stack in LDS, >= tree depth (the smaller, the more blocks per CU)
+hipError_t launch_megakernel_bvh(const Params &P, const float4 *blob, const Bvh &bvh, uint32_t stack_entries, float *accum,
                                  unsigned long long *counters, bool count, hipStream_t st) {
     uint32_t tiles_y = (P.height + 15u) / 16u;
     dim3 grid(P.tiles_x * tiles_y), block(256);
     if (count)
-        hipLaunchKernelGGL(pt_megakernel_bvh<true>, grid, block, 0, st, P, blob, bvh, accum, counters);
+        hipLaunchKernelGGL(pt_megakernel_bvh<true>, grid, block, (size_t)stack_entries * 256 * 4, st, P, blob, bvh, accum, counters);
     else
-        hipLaunchKernelGGL(pt_megakernel_bvh<false>, grid, block, 0, st, P, blob, bvh, accum, counters);
+        hipLaunchKernelGGL(pt_megakernel_bvh<false>, grid, block, (size_t)stack_entries * 256 * 4, st, P, blob, bvh, accum, counters);
     return hipGetLastError();
 }
 
