@@ -294,10 +294,10 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
     uint64_t pixels = (uint64_t)P.width * P.height;
     bool wavefront = (o.flags & HIPPT_FLAG_WAVEFRONT) != 0;
     if (wavefront) {
-        if (use_bvh || !lds || count || P.n_mat > 0xffffu || P.max_depth > 31u)
-            return hippt_set_error(HIPPT_ERR_INVALID, "the wavefront variant supports LDS-sized scenes without LBVH/counters, "
+        if ((!use_bvh && !lds) || count || P.n_mat > 0xffffu || P.max_depth > 31u)
+            return hippt_set_error(HIPPT_ERR_INVALID, "the wavefront variants support LDS-sized scenes or LBVH scenes, no counters, "
                                                       "<= 65535 materials and max_depth <= 31");
-        size_t need = pt::wf_workspace_bytes((uint32_t)pixels);
+        size_t need = use_bvh ? pt::wfb_workspace_bytes((uint32_t)pixels, P.n_light) : pt::wf_workspace_bytes((uint32_t)pixels);
         if (need > ctx->wf_ws_bytes) {
             HIP_TRY(hipStreamSynchronize(st));
             if (ctx->wf_ws) HIP_TRY(hipFree(ctx->wf_ws));
@@ -322,11 +322,13 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
         }
         auto &ev = ctx->ev_pool[ctx->ev_used++];
         HIP_TRY(hipEventRecord(ev.first, st));
-        if (wavefront)
+        const uint32_t stack_entries = (uint32_t)std::min(pt::BVH_STACK, std::max(8, ctx->bvh_depth + 2));
+        if (wavefront && use_bvh)
+            HIP_TRY(pt::wavefront_bvh_render(P, ctx->d_blob, bvh_view(ctx->bvh), stack_entries, d_accum, ctx->wf_ws, st, nullptr));
+        else if (wavefront)
             HIP_TRY(pt::wavefront_render(P, ctx->d_blob, d_accum, ctx->wf_ws, st, nullptr));
         else if (use_bvh)
-            HIP_TRY(pt::launch_megakernel_bvh(P, ctx->d_blob, bvh_view(ctx->bvh), (uint32_t)std::min(pt::BVH_STACK, std::max(8, ctx->bvh_depth + 2)),
-                                              d_accum, ctx->d_counters, count, st));
+            HIP_TRY(pt::launch_megakernel_bvh(P, ctx->d_blob, bvh_view(ctx->bvh), stack_entries, d_accum, ctx->d_counters, count, st));
         else
             HIP_TRY(pt::launch_megakernel(P, ctx->d_blob, d_accum, ctx->d_counters, count, lds, st));
         HIP_TRY(hipEventRecord(ev.second, st));

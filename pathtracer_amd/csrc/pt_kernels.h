@@ -20,6 +20,10 @@ hipError_t launch_unit_intersect_bvh(const Params &P, const float4 *blob, const 
                                      const float *rd, float *t, float *nn, int32_t *idx, hipStream_t st);
 // pt_wavefront.hip
 size_t wf_workspace_bytes(uint32_t n_pixels);
+// queue pipeline with persistent LBVH traversal kernels for many-sphere scenes (pt_wavefront_bvh.hip)
+size_t wfb_workspace_bytes(uint32_t n_pixels, uint32_t n_light);
+hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &bvh, uint32_t stack_entries, float *accum,
+                                void *workspace, hipStream_t st, uint32_t *iterations_out);
 hipError_t wavefront_render(const Params &P, const float4 *blob, float *accum, void *workspace, hipStream_t st,
                             uint32_t *iterations_out);
 hipError_t launch_resolve(const float *accum, uint32_t n_pixels, uint32_t spp, uint8_t *rgba, hipStream_t st);

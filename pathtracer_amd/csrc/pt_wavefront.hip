@@ -20,62 +20,9 @@
 // stream per (pixel, sample), so both variants render the same image.
 #include "pt_kernels.h"
 #include "pt_trace.h"
+#include "pt_wfqueue.h"
 
 namespace pt {
-
-// A queue carries the path state of its entries, SoA over queue positions: plane k of entry i is
-// f[k * cap + i] / u[k * cap + i]. Kernels read entry i with lane-consecutive i (coalesced) and
-// append to output queues at base + rank-in-wave (coalesced per wave).
-enum { F_RO = 0, F_RD = 3, F_T = 6, F_SUM = 9, F_X = 12, F_N = 15, NF = 18 };
-enum { U_PIX = 0, U_RNG0, U_RNG1, U_META, U_NEXT, U_MAT, NU };
-// U_META: bit 0 alive, bits 1-5 depth, bit 6 pending vertex is a scatter, bits 8.. media+1
-// U_NEXT: next global sample index of this pixel; U_MAT: material of the pending vertex | (next_media+1) << 16
-struct WfQueue {
-    float *f;
-    uint32_t *u;
-    uint32_t *count;
-    uint32_t cap;
-    __device__ __forceinline__ F3 ld3(int k, uint32_t i) const {
-        return F3{f[(size_t)k * cap + i], f[(size_t)(k + 1) * cap + i], f[(size_t)(k + 2) * cap + i]};
-    }
-    __device__ __forceinline__ void st3(int k, uint32_t i, F3 v) const {
-        f[(size_t)k * cap + i] = v.x;
-        f[(size_t)(k + 1) * cap + i] = v.y;
-        f[(size_t)(k + 2) * cap + i] = v.z;
-    }
-    __device__ __forceinline__ uint32_t ldu(int k, uint32_t i) const { return u[(size_t)k * cap + i]; }
-    __device__ __forceinline__ void stu(int k, uint32_t i, uint32_t v) const { u[(size_t)k * cap + i] = v; }
-};
-
-// Reserves queue positions for the lanes of a 256-thread block: wave ballot + prefix popcount,
-// wave totals combined through LDS, ONE atomicAdd per block and queue (a per-wave atomic on the
-// single queue counter serialises: 65k same-address atomics per launch took ~0.5 ms).
-// Every thread of the block must call it. Returns this lane's position in queue 0 / queue 1.
-__device__ __forceinline__ void queue_reserve2(bool want0, uint32_t *count0, uint32_t &pos0, bool want1, uint32_t *count1,
-                                               uint32_t &pos1, uint32_t (*s_cnt)[4], uint32_t *s_base) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    unsigned long long m0 = __ballot(want0), m1 = __ballot(want1);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (lane == 0) {
-        s_cnt[0][wave] = (uint32_t)__popcll(m0);
-        s_cnt[1][wave] = (uint32_t)__popcll(m1);
-    }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-        uint32_t *cnt = threadIdx.x == 0 ? count0 : count1;
-        uint32_t tot = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
-        s_base[threadIdx.x] = (tot && cnt) ? atomicAdd(cnt, tot) : 0u;
-    }
-    __syncthreads();
-    uint32_t off0 = 0, off1 = 0;
-    for (uint32_t w = 0; w < wave; ++w) {
-        off0 += s_cnt[0][w];
-        off1 += s_cnt[1][w];
-    }
-    pos0 = s_base[0] + off0 + (uint32_t)__popcll(m0 & below);
-    pos1 = s_base[1] + off1 + (uint32_t)__popcll(m1 & below);
-    __syncthreads();  // s_cnt / s_base are reused by the next trip
-}
 
 __global__ __launch_bounds__(256) void wf_init(WfQueue Q, uint32_t n, uint32_t sample_begin) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;

@@ -1,0 +1,570 @@
+// pt_wavefront_bvh.hip — queue-based pipeline for many-sphere scenes (BASELINE config C4).
+//
+// On the 7-object scenes the megakernel wins. With 100 000 spheres behind an LBVH the
+// picture turns: traversal lengths are long-tailed (a ray skimming the ground visits hundreds of nodes,
+// its wave neighbours a dozen), and a lane that owns a path must sit through its wave's longest
+// traversal — rocprofv3 counts 8 of 64 lanes active per VALU instruction in the BVH megakernel
+// (profiles/r01_c4_lbvh_pmc_summary.txt). Here rays live in queues and the two traversal kernels are
+// PERSISTENT: a lane that finishes its ray takes the next one from the queue (wave-aggregated ranges,
+// one atomic per 256 rays), so a wave is refilled while it runs, and the traversal kernels are lean
+// enough for 8 waves per SIMD. Per round:
+//
+//   wfb_traverse<false> : closest sphere through the LBVH for every entry of the ray queue
+//   wfb_logic           : planes + winner refinement (pt_device.h: refine_hit), medium free flight,
+//                         classification; glass / miss handled here; opaque / scatter vertices go to the
+//                         shade queue; a finished path is replaced by the pixel's next camera path
+//   wfb_nee_gen         : draws the 4 L light samples of every shade-queue entry (renderer.rs:35-46)
+//                         and writes them as shadow rays
+//   wfb_traverse<true>  : any sphere hit for every shadow ray
+//   wfb_shade           : plane occlusion, BRDF evaluation (renderer.rs:49-82), Russian roulette, lobe
+//                         sampling (renderer.rs:323-349) or phase-function scatter (:269-286)
+//
+// The arithmetic is the device code of the megakernels (pt_device.h, pt_bvh.h) with the same RNG stream
+// per (pixel, sample) and the same draw order, so the image equals the BVH megakernel's.
+#include "pt_kernels.h"
+#include "pt_trace.h"
+#include "pt_wfqueue.h"
+
+namespace pt {
+
+namespace {
+
+constexpr uint32_t kFetchChunk = 256;  // rays a wave reserves with one atomic
+constexpr uint32_t kFetchMin = 16;     // idle lanes that trigger a refill
+
+// renderer.rs:170-178: the pixel's next camera path
+__device__ __forceinline__ void new_camera_path(const Params &P, uint32_t seed_mixed, uint32_t pix, uint32_t &next, Rng &rng,
+                                                F3 &ro, F3 &rd, F3 &T, uint32_t &depth, int &media) {
+    uint32_t px = pix % P.width, py = pix / P.width;
+    rng.seed(seed_mixed, mix32(pix + seed_mixed), next);
+    float jx = rng.gen(), jy = rng.gen(), ds = rng.gen(), dt = rng.gen();
+    camera_ray(P, px, py, jx, jy, ds, dt, ro, rd);
+    T = F3{1, 1, 1};
+    depth = 0;
+    media = -1;
+    ++next;
+}
+
+__device__ __forceinline__ void push_ray(const WfQueue &Q, uint32_t pos, uint32_t pix, uint32_t depth, int media, uint32_t next, F3 sum,
+                                         F3 ro, F3 rd, F3 T, const Rng &rng) {
+    Q.stu(U_PIX, pos, pix);
+    Q.stu(U_META, pos, 1u | (depth << 1) | ((uint32_t)(media + 1) << 8));
+    Q.stu(U_NEXT, pos, next);
+    Q.st3(F_SUM, pos, sum);
+    Q.st3(F_RO, pos, ro);
+    Q.st3(F_RD, pos, rd);
+    Q.st3(F_T, pos, T);
+    Q.stu(U_RNG0, pos, rng.s0);
+    Q.stu(U_RNG1, pos, rng.s1);
+}
+
+}  // namespace
+
+// Every pixel starts with the camera path of its first sample; entries of the ray queue are always live rays.
+__global__ __launch_bounds__(256) void wfb_init(Params P, WfQueue Q, uint32_t n) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
+    uint32_t next = P.sample_begin, depth;
+    int media;
+    Rng rng{0u, 1u};
+    F3 ro, rd, T;
+    new_camera_path(P, seed_mixed, i, next, rng, ro, rd, T, depth, media);
+    push_ray(Q, i, i, depth, media, next, F3{0, 0, 0}, ro, rd, T, rng);
+    if (i == 0) *Q.count = n;
+}
+
+// Persistent LBVH traversal over a ray array. ANY = false: closest sphere of ray i = entry i of Q
+// (same result as pt_bvh.h: bvh_closest); out: hit_t[i], hit_leaf[i] (-1: none). ANY = true: shadow ray
+// r = k * count + e is sample k of shade-queue entry e (origin Q.F_X[e] + 1e-4 l, direction l and
+// tmax from the sample planes); out: occ[k * cap + e] (same result as bvh_any).
+template <bool ANY>
+__global__ __launch_bounds__(256) void wfb_traverse(Bvh bvh, WfQueue Q, const float *__restrict__ samples,
+                                                    uint32_t rays_per_entry, uint32_t *__restrict__ head,
+                                                    float *__restrict__ hit_t, int *__restrict__ hit_leaf,
+                                                    uint8_t *__restrict__ occ_out) {
+    extern __shared__ uint32_t s_stack[];  // stack_entries x 256
+    uint32_t *stack = s_stack + threadIdx.x;
+    const uint32_t stride = 256u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t count = *Q.count;
+    const uint32_t n_rays = count * rays_per_entry;
+    const size_t cap = Q.cap;
+
+    uint32_t w_next = 0, w_end = 0;  // this wave's reserved range of ray indices (wave-uniform)
+    bool exhausted = false;          // the global queue has no ray left (wave-uniform)
+    bool has = false;
+    uint32_t out_idx = 0;
+    RayK r{};
+    BoxRay br{};
+    float best_t = __builtin_inff(), lim = 0.0f, t_max = 0.0f;
+    int best = -1;
+    uint32_t best_ord = 0xffffffffu;
+    int node = 0, sp = 0;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!has);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle >= kFetchMin) {
+            if (w_next == w_end && !exhausted) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(head, kFetchChunk);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base >= n_rays) {
+                    exhausted = true;
+                } else {
+                    w_next = base;
+                    w_end = min(base + kFetchChunk, n_rays);
+                }
+            }
+            const uint32_t avail = w_end - w_next;
+            if (avail != 0u) {
+                uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (!has && rank < avail) {
+                    uint32_t ridx = w_next + rank;
+                    if (ANY) {
+                        uint32_t k = ridx / count, e = ridx - k * count;
+                        const float *sp5 = samples + (size_t)k * 5 * cap + e;
+                        F3 l = F3{sp5[0], sp5[cap], sp5[2 * cap]};
+                        float tmax = sp5[3 * cap];
+                        F3 x = Q.ld3(F_X, e);
+                        r = make_ray(madd(x, l, 1e-4f), l);
+                        lim = tmax * tmax;
+                        t_max = fsqrt(lim) * 1.000001f;
+                        out_idx = k * (uint32_t)cap + e;
+                    } else {
+                        r = make_ray(Q.ld3(F_RO, ridx), Q.ld3(F_RD, ridx));
+                        best_t = __builtin_inff();
+                        best = -1;
+                        best_ord = 0xffffffffu;
+                        out_idx = ridx;
+                    }
+                    br = make_box_ray(r.ro, r.rd);
+                    node = 0;
+                    sp = 0;
+                    has = true;
+                }
+                w_next += min(n_idle, avail);
+            } else if (n_idle == 64u) {
+                break;  // exhausted and every lane is done
+            }
+        }
+        if (!has) continue;
+
+        // ---- one node (pt_bvh.h: bvh_closest / bvh_any loop body) ----
+        float4 n0 = bvh.nodes[node * 4 + 0], n1 = bvh.nodes[node * 4 + 1], n2 = bvh.nodes[node * 4 + 2],
+               n3 = bvh.nodes[node * 4 + 3];
+        int left = (int)__float_as_uint(n3.x), right = (int)__float_as_uint(n3.y);
+        const float bound = ANY ? t_max : best_t;
+        float tl = box_entry(br, F3{n0.x, n0.y, n0.z}, F3{n0.w, n1.x, n1.y}, bound);
+        float tr = box_entry(br, F3{n1.z, n1.w, n2.x}, F3{n2.y, n2.z, n2.w}, bound);
+        bool hl = tl < __builtin_inff(), hr = tr < __builtin_inff();
+        bool finished = false;
+        if (ANY) {
+            bool occ = false;
+            if (hl && left < 0) {
+                float t = sphere_t(r, bvh.sph[~left]);
+                occ = occ | ((t > 0.0f) & (t * t < lim));
+                hl = false;
+            }
+            if (hr && right < 0) {
+                float t = sphere_t(r, bvh.sph[~right]);
+                occ = occ | ((t > 0.0f) & (t * t < lim));
+                hr = false;
+            }
+            if (occ) {
+                occ_out[out_idx] = 1;
+                finished = true;
+            }
+        } else {
+            auto leaf = [&](int lf) {
+                float t = sphere_t(r, bvh.sph[lf]);
+                if (t > 0.0f && t <= best_t) {
+                    uint32_t ord = __float_as_uint(bvh.aux[lf].z);
+                    if (t < best_t || ord < best_ord) {  // renderer.rs:359-361: first minimum in scene order
+                        best_t = t;
+                        best = lf;
+                        best_ord = ord;
+                    }
+                }
+            };
+            if (hl && left < 0) {
+                leaf(~left);
+                hl = false;
+            }
+            if (hr && right < 0) {
+                leaf(~right);
+                hr = false;
+            }
+        }
+        if (!finished) {
+            if (hl && hr) {
+                bool lfirst = ANY ? true : (tl <= tr);
+                stack[sp * stride] = (uint32_t)(lfirst ? right : left);
+                ++sp;
+                node = lfirst ? left : right;
+            } else if (hl || hr) {
+                node = hl ? left : right;
+            } else if (sp == 0) {
+                finished = true;
+                if (ANY) {
+                    occ_out[out_idx] = 0;
+                } else {
+                    hit_t[out_idx] = best_t;
+                    hit_leaf[out_idx] = best;
+                }
+            } else {
+                --sp;
+                node = (int)stack[sp * stride];
+            }
+        }
+        if (finished) has = false;
+    }
+}
+
+// Everything of one path vertex that follows the closest-sphere query and precedes next-event estimation.
+__global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restrict__ blob, Bvh bvh, WfQueue Qin,
+                                                 const float *__restrict__ hit_t, const int *__restrict__ hit_leaf,
+                                                 WfQueue Qnext, WfQueue Qshade, float *__restrict__ accum) {
+    __shared__ uint32_t s_cnt[2][4], s_base[2];
+    TblGlobal tbl{blob};
+    Tracer<TblGlobal, false, true> tr(P, tbl, bvh, nullptr);
+    const uint32_t count = *Qin.count;
+    const uint32_t s_end = P.sample_begin + P.sample_count;
+    const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
+    for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+        uint32_t qi = base + threadIdx.x;
+        bool act = qi < count;
+        bool to_next = false, to_shade = false;
+        uint32_t pix = 0, next = 0, depth = 0, mat_word = 0;
+        int media = -1;
+        bool scatter = false;
+        Rng rng{0u, 1u};
+        F3 ro = F3{0, 0, 0}, rd = F3{0, 0, 1}, T = F3{1, 1, 1}, sum = F3{0, 0, 0}, x = F3{0, 0, 0}, nn = F3{0, 1, 0};
+        if (act) {
+            pix = Qin.ldu(U_PIX, qi);
+            uint32_t meta = Qin.ldu(U_META, qi);
+            next = Qin.ldu(U_NEXT, qi);
+            sum = Qin.ld3(F_SUM, qi);
+            depth = (meta >> 1) & 31u;
+            media = (int)(meta >> 8) - 1;
+            ro = Qin.ld3(F_RO, qi);
+            rd = Qin.ld3(F_RD, qi);
+            T = Qin.ld3(F_T, qi);
+            rng.s0 = Qin.ldu(U_RNG0, qi);
+            rng.s1 = Qin.ldu(U_RNG1, qi);
+            bool alive = true;
+
+            // pt_trace.h: Tracer::closest after bvh_closest — planes, then the winner with the reference's roundings
+            RayK ray = make_ray(ro, rd);
+            float best_t = hit_t[qi];
+            int best = hit_leaf[qi];
+            closest_planes(tbl, P, ray, best_t, best, [&](int id) { return __float_as_uint(bvh.aux[id].z); });
+            HitRec h{best_t, best};
+            refine_hit(tbl, P, ray.ro, ray.rd, h, [&](int id) { return bvh.sph[id]; });
+
+            F3 A = F3{1, 1, 1};
+            float t_media = __builtin_inff();
+            if (media >= 0) {
+                Mat mm = load_mat(tbl, P.mat_off, (uint32_t)media);
+                t_media = -fln(rng.gen()) * rcp(mm.density);
+                float k = -mm.density * fminf(t_media, h.t);
+                A = F3{fexp(fmaxf(1.0f - mm.color.x, 0.0f) * k), fexp(fmaxf(1.0f - mm.color.y, 0.0f) * k),
+                       fexp(fmaxf(1.0f - mm.color.z, 0.0f) * k)};
+            }
+            if (t_media < h.t) {
+                T = T * A;
+                x = point_at_ref(ro, rd, t_media);
+                nn = F3{0.0f, 1.0f, 0.0f};
+                mat_word = (uint32_t)media | ((uint32_t)(media + 1) << 16);
+                scatter = true;
+                to_shade = true;
+            } else if (h.id < 0) {
+                alive = false;
+            } else {
+                uint32_t mid, order;
+                tr.finish(ray, h, x, nn, mid, order);
+                Mat m = load_mat(tbl, P.mat_off, mid);
+                int next_media = media;
+                if (m.density > 0.0f) next_media = (dot(-rd, nn) > 0.0f) ? (int)mid : -1;
+                T = T * A;
+                if (m.ior > 1.0f && m.metallic < 0.1f) {
+                    F3 nd = glass_dir(rd, nn, m.ior, rng.gen());
+                    ro = madd(x, nd, 1e-4f);
+                    rd = nd;
+                    media = next_media;
+                    ++depth;
+                    if (depth >= P.max_depth) alive = false;
+                } else {
+                    mat_word = mid | ((uint32_t)(next_media + 1) << 16);
+                    to_shade = true;
+                }
+            }
+            if (!to_shade) {
+                if (!alive && next < s_end) {  // the pixel's next sample takes the finished path's place
+                    new_camera_path(P, seed_mixed, pix, next, rng, ro, rd, T, depth, media);
+                    alive = true;
+                }
+                to_next = alive;
+                if (!to_next) {  // pixel done: its sum goes to the accumulator
+                    accum[3 * (size_t)pix + 0] += sum.x;
+                    accum[3 * (size_t)pix + 1] += sum.y;
+                    accum[3 * (size_t)pix + 2] += sum.z;
+                }
+            }
+        }
+        uint32_t pn, ps;
+        queue_reserve2(to_next, Qnext.count, pn, to_shade, Qshade.count, ps, s_cnt, s_base);
+        if (to_next) push_ray(Qnext, pn, pix, depth, media, next, sum, ro, rd, T, rng);
+        if (to_shade) {
+            Qshade.stu(U_PIX, ps, pix);
+            Qshade.stu(U_META, ps, 1u | (depth << 1) | (scatter ? 64u : 0u) | ((uint32_t)(media + 1) << 8));
+            Qshade.stu(U_NEXT, ps, next);
+            Qshade.stu(U_MAT, ps, mat_word);
+            Qshade.stu(U_RNG0, ps, rng.s0);
+            Qshade.stu(U_RNG1, ps, rng.s1);
+            Qshade.st3(F_SUM, ps, sum);
+            Qshade.st3(F_RD, ps, rd);
+            Qshade.st3(F_T, ps, T);
+            Qshade.st3(F_X, ps, x);
+            Qshade.st3(F_N, ps, nn);
+        }
+    }
+}
+
+// renderer.rs:35-46 for every entry of the shade queue: the 4 samples of every light, in the draw order of
+// pt_trace.h: direct_light. Sample k = light * 4 + s, five planes each: l.x, l.y, l.z, tmax, 1 / dist2.
+__global__ __launch_bounds__(256) void wfb_nee_gen(Params P, const float4 *__restrict__ blob, WfQueue Qshade,
+                                                   float *__restrict__ samples) {
+    TblGlobal tbl{blob};
+    const uint32_t count = *Qshade.count;
+    const size_t cap = Qshade.cap;
+    for (uint32_t qi = blockIdx.x * 256u + threadIdx.x; qi < count; qi += gridDim.x * 256u) {
+        Rng rng{Qshade.ldu(U_RNG0, qi), Qshade.ldu(U_RNG1, qi)};
+        F3 x = Qshade.ld3(F_X, qi);
+        for (uint32_t li = 0; li < P.n_light; ++li) {
+            uint32_t o = P.light_off + li * LIGHT_F4;
+            float4 l0 = tbl.ld(o), l1 = tbl.ld(o + 1), l2 = tbl.ld(o + 2);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float e1 = rng.gen() - 0.5f;
+                float e2 = rng.gen() - 0.5f;
+                F3 lp = f3(l0) + f3(l1) * e1 + f3(l2) * e2;
+                F3 lvec = lp - x;
+                float dist2 = dot(lvec, lvec);
+                float inv = rsq(dist2);
+                F3 l = lvec * inv;
+                float *sp5 = samples + (size_t)(li * 4 + s) * 5 * cap + qi;
+                sp5[0] = l.x;
+                sp5[cap] = l.y;
+                sp5[2 * cap] = l.z;
+                sp5[3 * cap] = (dist2 * inv) * 0.99949987493746f;  // |lvec| sqrt(0.999)
+                sp5[4 * cap] = inv * inv;
+            }
+        }
+        Qshade.stu(U_RNG0, qi, rng.s0);
+        Qshade.stu(U_RNG1, qi, rng.s1);
+    }
+}
+
+__global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restrict__ blob, WfQueue Qshade,
+                                                 const float *__restrict__ samples, const uint8_t *__restrict__ occ_sph,
+                                                 WfQueue Qnext, float *__restrict__ accum) {
+    __shared__ uint32_t s_cnt[2][4], s_base[2];
+    TblGlobal tbl{blob};
+    const uint32_t count = *Qshade.count;
+    const size_t cap = Qshade.cap;
+    const uint32_t s_end = P.sample_begin + P.sample_count;
+    const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
+    for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+        uint32_t qi = base + threadIdx.x;
+        bool act = qi < count;
+        bool to_next = false;
+        uint32_t pix = 0, next = 0, depth = 0;
+        int media = -1;
+        Rng rng{0u, 1u};
+        F3 ro = F3{0, 0, 0}, rd = F3{0, 0, 1}, T = F3{1, 1, 1}, sum = F3{0, 0, 0};
+        if (act) {
+            pix = Qshade.ldu(U_PIX, qi);
+            uint32_t meta = Qshade.ldu(U_META, qi);
+            next = Qshade.ldu(U_NEXT, qi);
+            uint32_t mw = Qshade.ldu(U_MAT, qi);
+            rng.s0 = Qshade.ldu(U_RNG0, qi);
+            rng.s1 = Qshade.ldu(U_RNG1, qi);
+            depth = (meta >> 1) & 31u;
+            bool scatter = meta & 64u;
+            media = (int)(meta >> 8) - 1;
+            uint32_t mid = mw & 0xffffu;
+            int next_media = (int)(mw >> 16) - 1;
+            F3 x = Qshade.ld3(F_X, qi), nn = Qshade.ld3(F_N, qi);
+            rd = Qshade.ld3(F_RD, qi);
+            T = Qshade.ld3(F_T, qi);
+            sum = Qshade.ld3(F_SUM, qi);
+            Mat m = load_mat(tbl, P.mat_off, mid);
+            ShadeK sk = make_shade(nn, -rd, m);
+
+            // pt_trace.h: direct_light, with the samples and their sphere occlusion already computed
+            F3 total = F3{0.0f, 0.0f, 0.0f};
+            for (uint32_t li = 0; li < P.n_light; ++li) {
+                uint32_t o = P.light_off + li * LIGHT_F4;
+                float4 l0 = tbl.ld(o), l3 = tbl.ld(o + 3), l4 = tbl.ld(o + 4);
+                F3 l[4];
+                float id2[4], tmax[4];
+                bool occ[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float *sp5 = samples + (size_t)(li * 4 + s) * 5 * cap + qi;
+                    l[s] = F3{sp5[0], sp5[cap], sp5[2 * cap]};
+                    tmax[s] = sp5[3 * cap];
+                    id2[s] = sp5[4 * cap];
+                    occ[s] = occ_sph[(size_t)(li * 4 + s) * cap + qi] != 0;
+                }
+                uint32_t c0 = 0, c1 = 0;
+                occluded_multi<TblGlobal, 4, false>(tbl, P, x, 1e-4f, l, tmax, occ, c0, c1, false);
+                F3 contrib = F3{0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (!occ[s]) {
+                        bool lit;
+                        F3 c = nee_eval(sk, l[s], id2[s], f3(l4), l0.w, f3(l3), lit);
+                        contrib = contrib + c;
+                    }
+                }
+                total = madd(total, contrib, 0.25f);  // :82
+            }
+            sum = sum + T * total;
+
+            bool alive = true;
+            if (scatter) {
+                float ct = sample_phase_function(m.aniso, rng.gen());
+                float up = rng.gen();
+                ro = x;
+                rd = scatter_dir(rd, ct, up);
+            } else {
+                float p = fmaxf(fmaxf(m.color.x, m.color.y), m.color.z);
+                bool cont = depth < 2u;
+                if (!cont) cont = rng.gen() < p;
+                if (cont) {
+                    F3 nd, f;
+                    if (rng.gen() < (1.0f - m.metallic)) {
+                        float up = rng.gen(), r2 = rng.gen();
+                        nd = diffuse_dir(nn, up, r2);
+                        f = m.color * 0.31830988618379067154f;
+                    } else {
+                        float r1 = rng.gen(), r2 = rng.gen();
+                        nd = reflect(rd, sample_ggx_h(nn, m.roughness, r1, r2));
+                        f = F3{1.0f, 1.0f, 1.0f};
+                    }
+                    float c = dot(nd, nn);
+                    if (c > 0.0f) {
+                        float w = depth >= 2u ? c * rcp(p) : c;
+                        T = T * f * w;
+                        ro = madd(x, nd, 1e-4f);
+                        rd = nd;
+                        media = next_media;
+                    } else {
+                        alive = false;
+                    }
+                } else {
+                    alive = false;
+                }
+            }
+            ++depth;
+            if (depth >= P.max_depth) alive = false;
+            if (!alive && next < s_end) {
+                new_camera_path(P, seed_mixed, pix, next, rng, ro, rd, T, depth, media);
+                alive = true;
+            }
+            to_next = alive;
+            if (!to_next) {
+                accum[3 * (size_t)pix + 0] += sum.x;
+                accum[3 * (size_t)pix + 1] += sum.y;
+                accum[3 * (size_t)pix + 2] += sum.z;
+            }
+        }
+        uint32_t pn, unused;
+        queue_reserve2(to_next, Qnext.count, pn, false, nullptr, unused, s_cnt, s_base);
+        if (to_next) push_ray(Qnext, pn, pix, depth, media, next, sum, ro, rd, T, rng);
+    }
+}
+
+// ---- host driver -----------------------------------------------------------------------
+namespace {
+struct WfbLayout {
+    size_t per_queue, hits, samples, occ, total;
+};
+WfbLayout wfb_layout(uint32_t n, uint32_t n_light) {
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    WfbLayout L;
+    L.per_queue = al((size_t)n * 4 * (NF + NU));
+    L.hits = al((size_t)n * 8);
+    L.samples = al((size_t)n * 4 * 5 * 4 * std::max(1u, n_light));
+    L.occ = al((size_t)n * 4 * std::max(1u, n_light));
+    L.total = 4096 + 3 * L.per_queue + L.hits + L.samples + L.occ;
+    return L;
+}
+}  // namespace
+
+size_t wfb_workspace_bytes(uint32_t n_pixels, uint32_t n_light) { return wfb_layout(n_pixels, n_light).total; }
+
+hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &bvh, uint32_t stack_entries, float *accum,
+                                void *workspace, hipStream_t st, uint32_t *iterations_out) {
+    const uint32_t n = P.width * P.height;
+    const WfbLayout L = wfb_layout(n, P.n_light);
+    uint8_t *w = (uint8_t *)workspace;
+    uint32_t *counters = (uint32_t *)w;  // [0],[1]: ray queue counts (ping-pong), [2]: shade count, [3],[4]: fetch heads
+    w += 4096;
+    WfQueue Q[3];
+    for (int k = 0; k < 3; ++k) {
+        Q[k].f = (float *)(w + L.per_queue * k);
+        Q[k].u = (uint32_t *)(w + L.per_queue * k + (size_t)n * 4 * NF);
+        Q[k].count = &counters[k];
+        Q[k].cap = n;
+    }
+    w += 3 * L.per_queue;
+    float *hit_t = (float *)w;
+    int *hit_leaf = (int *)(w + (size_t)n * 4);
+    w += L.hits;
+    float *samples = (float *)w;
+    w += L.samples;
+    uint8_t *occ = w;
+
+    const unsigned blocks_all = (n + 255) / 256;
+    const unsigned grid = std::min(blocks_all, 256u * 8u);
+    const unsigned grid_trav = 256u * 8u;  // persistent: every CU full at 8 waves per SIMD
+    const size_t stack_bytes = (size_t)stack_entries * 256 * 4;
+    hipError_t e;
+    if ((e = hipMemsetAsync(counters, 0, 4096, st)) != hipSuccess) return e;
+    if (P.sample_count == 0) return hipSuccess;
+    hipLaunchKernelGGL(wfb_init, dim3(blocks_all), dim3(256), 0, st, P, Q[0], n);
+    const uint32_t max_iter = P.sample_count * P.max_depth + 1;
+    uint32_t it = 0;
+    int cur = 0;
+    for (; it < max_iter; ++it) {
+        if ((e = hipMemsetAsync(&counters[1 - cur], 0, 4, st)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(&counters[2], 0, 12, st)) != hipSuccess) return e;  // shade count + both fetch heads
+        hipLaunchKernelGGL(wfb_traverse<false>, dim3(grid_trav), dim3(256), stack_bytes, st, bvh, Q[cur], (const float *)nullptr, 1u,
+                           &counters[3], hit_t, hit_leaf, (uint8_t *)nullptr);
+        hipLaunchKernelGGL(wfb_logic, dim3(grid), dim3(256), 0, st, P, blob, bvh, Q[cur], (const float *)hit_t,
+                           (const int *)hit_leaf, Q[1 - cur], Q[2], accum);
+        hipLaunchKernelGGL(wfb_nee_gen, dim3(grid), dim3(256), 0, st, P, blob, Q[2], samples);
+        hipLaunchKernelGGL(wfb_traverse<true>, dim3(grid_trav), dim3(256), stack_bytes, st, bvh, Q[2], (const float *)samples,
+                           4u * P.n_light, &counters[4], (float *)nullptr, (int *)nullptr, occ);
+        hipLaunchKernelGGL(wfb_shade, dim3(grid), dim3(256), 0, st, P, blob, Q[2], (const float *)samples, (const uint8_t *)occ,
+                           Q[1 - cur], accum);
+        cur = 1 - cur;
+        if ((it & 15u) == 15u) {
+            uint32_t left = 0;
+            if ((e = hipMemcpyAsync(&left, &counters[cur], 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+            if (left == 0) {
+                ++it;
+                break;
+            }
+        }
+    }
+    if (iterations_out) *iterations_out = it;
+    return hipGetLastError();
+}
+
+}  // namespace pt

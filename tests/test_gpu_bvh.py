@@ -102,3 +102,26 @@ def test_small_scene_can_force_bvh(example_scene):
     b = hip_renderer.render_accum(s, seed=1)
     err = np.abs(a - b).max(axis=2) / np.maximum(np.abs(b).max(axis=2), 1e-3)
     assert np.quantile(err, 0.99) < 1e-4
+
+
+def test_wavefront_bvh_pipeline_matches_bvh_megakernel(scene20k, oracle):
+    """Queue pipeline with persistent LBVH traversal kernels (pt_wavefront_bvh.hip) vs the BVH megakernel:
+    same device functions, same RNG streams and draw order -> the same image."""
+    from pathtracer_amd import _abi, hip_renderer
+    s = scene20k.with_render(160, 90, 6)
+    a, ca = hip_renderer.render_accum(s, seed=5, flags=_abi.FLAG_BVH, counters=True)
+    b = hip_renderer.render_accum(s, seed=5, flags=_abi.FLAG_BVH | _abi.FLAG_WAVEFRONT)
+    assert np.isfinite(b).all() and b.mean() > 0
+    err = np.abs(a - b).max(axis=2) / np.maximum(np.abs(a).max(axis=2), 1e-3 * 6)
+    assert np.quantile(err, 0.99) < 1e-4, np.quantile(err, [0.5, 0.9, 0.99, 1.0])
+    assert abs(a.sum(dtype=np.float64) - b.sum(dtype=np.float64)) < 1e-4 * a.sum(dtype=np.float64)
+    # sample ranges compose, uneven image size, more lights
+    s2 = scene20k.with_render(75, 41, 5)
+    s2.add_light((10, 25, 30), (6, 0, 0), (0, 0, 6), (30, 20, 10))
+    full = hip_renderer.render_accum(s2, 0, 5, seed=2, flags=_abi.FLAG_WAVEFRONT)
+    parts = (hip_renderer.render_accum(s2, 0, 2, seed=2, flags=_abi.FLAG_WAVEFRONT)
+             + hip_renderer.render_accum(s2, 2, 3, seed=2, flags=_abi.FLAG_WAVEFRONT))
+    assert np.allclose(full, parts, rtol=2e-6, atol=1e-6)
+    mk = hip_renderer.render_accum(s2, 0, 5, seed=2)
+    err = np.abs(full - mk).max(axis=2) / np.maximum(np.abs(mk).max(axis=2), 1e-3 * 5)
+    assert np.quantile(err, 0.99) < 1e-4
