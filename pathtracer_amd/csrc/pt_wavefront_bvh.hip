@@ -75,20 +75,20 @@ __global__ __launch_bounds__(256) void wfb_init(Params P, WfQueue Q, uint32_t n)
 }
 
 // Persistent LBVH traversal over a ray array. ANY = false: closest sphere of ray i = entry i of Q
-// (same result as pt_bvh.h: bvh_closest); out: hit_t[i], hit_leaf[i] (-1: none). ANY = true: shadow ray
-// r = k * count + e is sample k of shade-queue entry e (origin Q.F_X[e] + 1e-4 l, direction l and
-// tmax from the sample planes); out: occ[k * cap + e] (same result as bvh_any).
+// (same result as pt_bvh.h: bvh_closest); out: hit_t[i], hit_leaf[i] (-1: none). ANY = true: shadow ray r
+// is sample k of shade-queue entry e with ray_list[r] = k * cap + e (origin Q.F_X[e] + 1e-4 l, direction l
+// and tmax from the sample planes); out: occ[k * cap + e] (same result as bvh_any).
 template <bool ANY>
 __global__ __launch_bounds__(256) void wfb_traverse(Bvh bvh, WfQueue Q, const float *__restrict__ samples,
-                                                    uint32_t rays_per_entry, uint32_t *__restrict__ head,
+                                                    const uint32_t *__restrict__ ray_list, const uint32_t *__restrict__ ray_count,
+                                                    uint32_t *__restrict__ head,
                                                     float *__restrict__ hit_t, int *__restrict__ hit_leaf,
                                                     uint8_t *__restrict__ occ_out) {
     extern __shared__ uint32_t s_stack[];  // stack_entries x 256
     uint32_t *stack = s_stack + threadIdx.x;
     const uint32_t stride = 256u;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t count = *Q.count;
-    const uint32_t n_rays = count * rays_per_entry;
+    const uint32_t n_rays = ANY ? *ray_count : *Q.count;
     const size_t cap = Q.cap;
 
     uint32_t w_next = 0, w_end = 0;  // this wave's reserved range of ray indices (wave-uniform)
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void wfb_traverse(Bvh bvh, WfQueue Q, const fl
                 if (!has && rank < avail) {
                     uint32_t ridx = w_next + rank;
                     if (ANY) {
-                        uint32_t k = ridx / count, e = ridx - k * count;
+                        uint32_t ke = ray_list[ridx];  // sample k of shade-queue entry e, as k * cap + e
+                        uint32_t k = ke / (uint32_t)cap, e = ke - k * (uint32_t)cap;
                         const float *sp5 = samples + (size_t)k * 5 * cap + e;
                         F3 l = F3{sp5[0], sp5[cap], sp5[2 * cap]};
                         float tmax = sp5[3 * cap];
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void wfb_traverse(Bvh bvh, WfQueue Q, const fl
                         r = make_ray(madd(x, l, 1e-4f), l);
                         lim = tmax * tmax;
                         t_max = fsqrt(lim) * 1.000001f;
-                        out_idx = k * (uint32_t)cap + e;
+                        out_idx = ke;
                     } else {
                         r = make_ray(Q.ld3(F_RO, ridx), Q.ld3(F_RD, ridx));
                         best_t = __builtin_inff();
@@ -334,36 +335,59 @@ __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restr
 
 // renderer.rs:35-46 for every entry of the shade queue: the 4 samples of every light, in the draw order of
 // pt_trace.h: direct_light. Sample k = light * 4 + s, five planes each: l.x, l.y, l.z, tmax, 1 / dist2.
+// A sample that faces away (n.l <= 0 or the light's back side, renderer.rs:50,55) contributes nothing
+// whether it is occluded or not, so it gets no shadow ray: its occlusion byte is preset to 1, and only the
+// other samples are appended to the shadow-ray list.
 __global__ __launch_bounds__(256) void wfb_nee_gen(Params P, const float4 *__restrict__ blob, WfQueue Qshade,
-                                                   float *__restrict__ samples) {
+                                                   float *__restrict__ samples, uint8_t *__restrict__ occ,
+                                                   uint32_t *__restrict__ ray_list, uint32_t *__restrict__ ray_count) {
+    __shared__ uint32_t s_cnt[2][4], s_base[2];
     TblGlobal tbl{blob};
     const uint32_t count = *Qshade.count;
     const size_t cap = Qshade.cap;
-    for (uint32_t qi = blockIdx.x * 256u + threadIdx.x; qi < count; qi += gridDim.x * 256u) {
-        Rng rng{Qshade.ldu(U_RNG0, qi), Qshade.ldu(U_RNG1, qi)};
-        F3 x = Qshade.ld3(F_X, qi);
+    for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+        const uint32_t qi = base + threadIdx.x;
+        const bool act = qi < count;
+        Rng rng{0u, 1u};
+        F3 x = F3{0, 0, 0}, nn = F3{0, 1, 0};
+        if (act) {
+            rng = Rng{Qshade.ldu(U_RNG0, qi), Qshade.ldu(U_RNG1, qi)};
+            x = Qshade.ld3(F_X, qi);
+            nn = Qshade.ld3(F_N, qi);
+        }
         for (uint32_t li = 0; li < P.n_light; ++li) {
             uint32_t o = P.light_off + li * LIGHT_F4;
-            float4 l0 = tbl.ld(o), l1 = tbl.ld(o + 1), l2 = tbl.ld(o + 2);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                float e1 = rng.gen() - 0.5f;
-                float e2 = rng.gen() - 0.5f;
-                F3 lp = f3(l0) + f3(l1) * e1 + f3(l2) * e2;
-                F3 lvec = lp - x;
-                float dist2 = dot(lvec, lvec);
-                float inv = rsq(dist2);
-                F3 l = lvec * inv;
-                float *sp5 = samples + (size_t)(li * 4 + s) * 5 * cap + qi;
-                sp5[0] = l.x;
-                sp5[cap] = l.y;
-                sp5[2 * cap] = l.z;
-                sp5[3 * cap] = (dist2 * inv) * 0.99949987493746f;  // |lvec| sqrt(0.999)
-                sp5[4 * cap] = inv * inv;
+            float4 l0 = tbl.ld(o), l1 = tbl.ld(o + 1), l2 = tbl.ld(o + 2), l4 = tbl.ld(o + 4);
+#pragma unroll 1
+            for (uint32_t s = 0; s < 4; ++s) {
+                bool want = false;
+                const uint32_t k = li * 4 + s;
+                if (act) {
+                    float e1 = rng.gen() - 0.5f;
+                    float e2 = rng.gen() - 0.5f;
+                    F3 lp = f3(l0) + f3(l1) * e1 + f3(l2) * e2;
+                    F3 lvec = lp - x;
+                    float dist2 = dot(lvec, lvec);
+                    float inv = rsq(dist2);
+                    F3 l = lvec * inv;
+                    float *sp5 = samples + (size_t)k * 5 * cap + qi;
+                    sp5[0] = l.x;
+                    sp5[cap] = l.y;
+                    sp5[2 * cap] = l.z;
+                    sp5[3 * cap] = (dist2 * inv) * 0.99949987493746f;  // |lvec| sqrt(0.999)
+                    sp5[4 * cap] = inv * inv;
+                    want = (dot(nn, l) > 0.0f) & (-dot(l, f3(l4)) > 0.0f);
+                    if (!want) occ[(size_t)k * cap + qi] = 1;
+                }
+                uint32_t pos, unused;
+                queue_reserve2(want, ray_count, pos, false, nullptr, unused, s_cnt, s_base);
+                if (want) ray_list[pos] = k * (uint32_t)cap + qi;
             }
         }
-        Qshade.stu(U_RNG0, qi, rng.s0);
-        Qshade.stu(U_RNG1, qi, rng.s1);
+        if (act) {
+            Qshade.stu(U_RNG0, qi, rng.s0);
+            Qshade.stu(U_RNG1, qi, rng.s1);
+        }
     }
 }
 
@@ -491,7 +515,7 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
 // ---- host driver -----------------------------------------------------------------------
 namespace {
 struct WfbLayout {
-    size_t per_queue, hits, samples, occ, total;
+    size_t per_queue, hits, samples, occ, list, total;
 };
 WfbLayout wfb_layout(uint32_t n, uint32_t n_light) {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -500,7 +524,8 @@ WfbLayout wfb_layout(uint32_t n, uint32_t n_light) {
     L.hits = al((size_t)n * 8);
     L.samples = al((size_t)n * 4 * 5 * 4 * std::max(1u, n_light));
     L.occ = al((size_t)n * 4 * std::max(1u, n_light));
-    L.total = 4096 + 3 * L.per_queue + L.hits + L.samples + L.occ;
+    L.list = al((size_t)n * 4 * 4 * std::max(1u, n_light));
+    L.total = 4096 + 3 * L.per_queue + L.hits + L.samples + L.occ + L.list;
     return L;
 }
 }  // namespace
@@ -512,7 +537,7 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
     const uint32_t n = P.width * P.height;
     const WfbLayout L = wfb_layout(n, P.n_light);
     uint8_t *w = (uint8_t *)workspace;
-    uint32_t *counters = (uint32_t *)w;  // [0],[1]: ray queue counts (ping-pong), [2]: shade count, [3],[4]: fetch heads
+    uint32_t *counters = (uint32_t *)w;  // [0],[1]: ray queue counts (ping-pong), [2]: shade count, [3],[4]: fetch heads, [5]: shadow-ray count
     w += 4096;
     WfQueue Q[3];
     for (int k = 0; k < 3; ++k) {
@@ -528,6 +553,8 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
     float *samples = (float *)w;
     w += L.samples;
     uint8_t *occ = w;
+    w += L.occ;
+    uint32_t *ray_list = (uint32_t *)w;
 
     const unsigned blocks_all = (n + 255) / 256;
     const unsigned grid = std::min(blocks_all, 256u * 8u);
@@ -542,14 +569,14 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
     int cur = 0;
     for (; it < max_iter; ++it) {
         if ((e = hipMemsetAsync(&counters[1 - cur], 0, 4, st)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(&counters[2], 0, 12, st)) != hipSuccess) return e;  // shade count + both fetch heads
-        hipLaunchKernelGGL(wfb_traverse<false>, dim3(grid_trav), dim3(256), stack_bytes, st, bvh, Q[cur], (const float *)nullptr, 1u,
-                           &counters[3], hit_t, hit_leaf, (uint8_t *)nullptr);
+        if ((e = hipMemsetAsync(&counters[2], 0, 16, st)) != hipSuccess) return e;  // shade count, both fetch heads, shadow-ray count
+        hipLaunchKernelGGL(wfb_traverse<false>, dim3(grid_trav), dim3(256), stack_bytes, st, bvh, Q[cur], (const float *)nullptr,
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, &counters[3], hit_t, hit_leaf, (uint8_t *)nullptr);
         hipLaunchKernelGGL(wfb_logic, dim3(grid), dim3(256), 0, st, P, blob, bvh, Q[cur], (const float *)hit_t,
                            (const int *)hit_leaf, Q[1 - cur], Q[2], accum);
-        hipLaunchKernelGGL(wfb_nee_gen, dim3(grid), dim3(256), 0, st, P, blob, Q[2], samples);
+        hipLaunchKernelGGL(wfb_nee_gen, dim3(grid), dim3(256), 0, st, P, blob, Q[2], samples, occ, ray_list, &counters[5]);
         hipLaunchKernelGGL(wfb_traverse<true>, dim3(grid_trav), dim3(256), stack_bytes, st, bvh, Q[2], (const float *)samples,
-                           4u * P.n_light, &counters[4], (float *)nullptr, (int *)nullptr, occ);
+                           (const uint32_t *)ray_list, (const uint32_t *)&counters[5], &counters[4], (float *)nullptr, (int *)nullptr, occ);
         hipLaunchKernelGGL(wfb_shade, dim3(grid), dim3(256), 0, st, P, blob, Q[2], (const float *)samples, (const uint8_t *)occ,
                            Q[1 - cur], accum);
         cur = 1 - cur;
