@@ -153,8 +153,9 @@ def main():
             "config": {"workload": f"{args.config.upper()}: {scene_name} {W}x{H}, {SPP} spp per GPU ({SPP * world} spp image), "
                                    f"max_depth {args.max_depth}, seed 0",
                        "parallelism": f"sample-range split over {world} GPU(s), one RCCL reduce" if world > 1 else "1 GPU",
-                       "kernel": "wavefront" if args.flags & _abi.FLAG_WAVEFRONT else
-                                 ("megakernel+lbvh" if len(scene.spheres) >= 64 and not args.flags & _abi.FLAG_NO_BVH else "megakernel"),
+                       "kernel": ("wavefront+lbvh" if not args.flags & _abi.FLAG_MEGAKERNEL else "megakernel+lbvh")
+                                 if len(scene.spheres) >= 64 and not args.flags & _abi.FLAG_NO_BVH else
+                                 ("wavefront" if args.flags & _abi.FLAG_WAVEFRONT else "megakernel"),
                        "tables": "global" if (args.flags & _abi.FLAG_TABLES_GLOBAL or len(scene.spheres) >= 64) else "lds"},
             "mrays_per_s": round(flops.rays(cn) * world / (elapsed / args.steps) / 1e6, 1),
             "pct_fp32_valu_peak": round(100.0 * achieved / FP32_VALU_PEAK_TFLOPS, 2),

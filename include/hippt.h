@@ -114,11 +114,12 @@ typedef struct hippt_scene {
 
 /* flags */
 #define HIPPT_FLAG_COUNTERS 1u   /* run the event-counting variant          */
-#define HIPPT_FLAG_WAVEFRONT 2u  /* queue-based extend/shade/shadow pipeline */
+#define HIPPT_FLAG_WAVEFRONT 2u  /* queue-based extend/shade/shadow pipeline (the default for LBVH scenes) */
 #define HIPPT_FLAG_BVH 4u        /* LBVH over the sphere table               */
 #define HIPPT_FLAG_NO_BVH 8u     /* force the brute-force object loop        */
 #define HIPPT_FLAG_TABLES_GLOBAL 16u /* read scene tables from global memory
                                         (scalar loads) instead of staging in LDS */
+#define HIPPT_FLAG_MEGAKERNEL 32u /* force the one-kernel variant (the default for scenes without LBVH) */
 
 typedef struct hippt_options {
     uint32_t sample_begin; /* first global sample index rendered by this call */

@@ -293,6 +293,11 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
     }
     uint64_t pixels = (uint64_t)P.width * P.height;
     bool wavefront = (o.flags & HIPPT_FLAG_WAVEFRONT) != 0;
+    if ((o.flags & HIPPT_FLAG_WAVEFRONT) && (o.flags & HIPPT_FLAG_MEGAKERNEL))
+        return hippt_set_error(HIPPT_ERR_INVALID, "HIPPT_FLAG_WAVEFRONT and HIPPT_FLAG_MEGAKERNEL are exclusive");
+    // LBVH scenes default to the queue pipeline with persistent traversal kernels (2.4x the BVH megakernel on the
+    // 100 000-sphere scene); the counting variant exists only as a megakernel
+    if (use_bvh && !(o.flags & HIPPT_FLAG_MEGAKERNEL) && !count && P.n_mat <= 0xffffu && P.max_depth <= 31u) wavefront = true;
     if (wavefront) {
         if ((!use_bvh && !lds) || count || P.n_mat > 0xffffu || P.max_depth > 31u)
             return hippt_set_error(HIPPT_ERR_INVALID, "the wavefront variants support LDS-sized scenes or LBVH scenes, no counters, "

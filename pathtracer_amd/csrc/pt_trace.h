@@ -81,8 +81,10 @@ struct Tracer {
             if constexpr (BVH) {
 #pragma unroll 1
                 for (int s = 0; s < 4; ++s) {
+                    // a sample that faces away contributes nothing (:50,:55) whether occluded or not: no traversal
+                    bool facing = (dot(sk.n, l[s]) > 0.0f) & (-dot(l[s], f3(l4)) > 0.0f);
                     uint32_t nt = 0;
-                    occ[s] = bvh_any(bvh, make_ray(madd(x, l[s], 1e-4f), l[s]), tmax[s] * tmax[s], stack, 256u, nt);
+                    occ[s] = facing ? bvh_any(bvh, make_ray(madd(x, l[s], 1e-4f), l[s]), tmax[s] * tmax[s], stack, 256u, nt) : true;
                     bump(HIPPT_C_SHADOW_SPHERE_TESTS, nt);
                 }
             }

@@ -29,8 +29,14 @@ namespace pt {
 
 namespace {
 
-constexpr uint32_t kFetchChunk = 256;  // rays a wave reserves with one atomic
-constexpr uint32_t kFetchMin = 16;     // idle lanes that trigger a refill
+#ifndef WFB_FETCH_MIN
+#define WFB_FETCH_MIN 16
+#endif
+#ifndef WFB_ANY_NEAR_FIRST
+#define WFB_ANY_NEAR_FIRST 0
+#endif
+constexpr uint32_t kFetchChunk = 256;          // rays a wave reserves with one atomic
+constexpr uint32_t kFetchMin = WFB_FETCH_MIN;  // idle lanes that trigger a refill
 
 // renderer.rs:170-178: the pixel's next camera path
 __device__ __forceinline__ void new_camera_path(const Params &P, uint32_t seed_mixed, uint32_t pix, uint32_t &next, Rng &rng,
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(256) void wfb_traverse(Bvh bvh, WfQueue Q, const fl
         }
         if (!finished) {
             if (hl && hr) {
-                bool lfirst = ANY ? true : (tl <= tr);
+                bool lfirst = (ANY && !WFB_ANY_NEAR_FIRST) ? true : (tl <= tr);
                 stack[sp * stride] = (uint32_t)(lfirst ? right : left);
                 ++sp;
                 node = lfirst ? left : right;

@@ -109,7 +109,7 @@ def test_wavefront_bvh_pipeline_matches_bvh_megakernel(scene20k, oracle):
     same device functions, same RNG streams and draw order -> the same image."""
     from pathtracer_amd import _abi, hip_renderer
     s = scene20k.with_render(160, 90, 6)
-    a, ca = hip_renderer.render_accum(s, seed=5, flags=_abi.FLAG_BVH, counters=True)
+    a, ca = hip_renderer.render_accum(s, seed=5, flags=_abi.FLAG_BVH | _abi.FLAG_MEGAKERNEL, counters=True)
     b = hip_renderer.render_accum(s, seed=5, flags=_abi.FLAG_BVH | _abi.FLAG_WAVEFRONT)
     assert np.isfinite(b).all() and b.mean() > 0
     err = np.abs(a - b).max(axis=2) / np.maximum(np.abs(a).max(axis=2), 1e-3 * 6)
@@ -122,6 +122,6 @@ def test_wavefront_bvh_pipeline_matches_bvh_megakernel(scene20k, oracle):
     parts = (hip_renderer.render_accum(s2, 0, 2, seed=2, flags=_abi.FLAG_WAVEFRONT)
              + hip_renderer.render_accum(s2, 2, 3, seed=2, flags=_abi.FLAG_WAVEFRONT))
     assert np.allclose(full, parts, rtol=2e-6, atol=1e-6)
-    mk = hip_renderer.render_accum(s2, 0, 5, seed=2)
+    mk = hip_renderer.render_accum(s2, 0, 5, seed=2, flags=_abi.FLAG_MEGAKERNEL)
     err = np.abs(full - mk).max(axis=2) / np.maximum(np.abs(mk).max(axis=2), 1e-3 * 5)
     assert np.quantile(err, 0.99) < 1e-4

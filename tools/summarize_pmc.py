@@ -10,9 +10,9 @@ tot = defaultdict(lambda: defaultdict(float))
 for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "megakernel" not in k and "wf_" not in k:
+        if "megakernel" not in k and "wf_" not in k and "wfb_" not in k:
             continue
-        short = k.split("(")[0].replace("void pt::", "")
+        short = k.split("(")[0].replace("void pt::", "").replace("pt::", "")
         tot[short][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, c in sorted(tot.items()):
     print(f"== {k}")
