@@ -173,7 +173,10 @@ int build_bvh(const float4 *d_blob, const pt::Params &P, pt::BvhBuffers &out, hi
     }
     return HIPPT_OK;
 }
-pt::Bvh bvh_view(const pt::BvhBuffers &b) { return pt::Bvh{b.nodes, b.sph_sorted, b.aux_sorted, b.n}; }
+pt::Bvh bvh_view(const pt::BvhBuffers &b) {
+    return pt::Bvh{b.nodes, b.sph_sorted, b.aux_sorted, b.n, {b.grid_lo[0], b.grid_lo[1], b.grid_lo[2]},
+                   {b.grid_cell[0], b.grid_cell[1], b.grid_cell[2]}};
+}
 }  // namespace
 
 struct hippt_context {

@@ -12,17 +12,38 @@
 
 namespace pt {
 
-// Node = 4 x float4 (64 B, one cache line):
-//   n0 = {Llo.x, Llo.y, Llo.z, Lhi.x}  n1 = {Lhi.y, Lhi.z, Rlo.x, Rlo.y}
-//   n2 = {Rlo.z, Rhi.x, Rhi.y, Rhi.z}  n3 = {left, right, -, -}  (int bits)
+// Node = 2 x uint4 (32 B): per child {lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, child},
+// box faces on a 16-bit grid over the root box, rounded outwards at build time (pt_bvh_build.hip) — the
+// traversal kernels are bound by the number of vector-L1 accesses per node (each lane reads its own node:
+// one access per lane and 16-byte load), so two loads per node instead of four is what matters.
 // child >= 0: internal node index; child < 0: leaf ~child = position in the
 // Morton-sorted sphere arrays.
 struct Bvh {
-    const float4 *__restrict__ nodes;
+    const uint4 *__restrict__ nodes;
     const float4 *__restrict__ sph;  // sorted {c, r*r}
     const float4 *__restrict__ aux;  // sorted {1/r, material, scene order, 0}
     uint32_t n;                      // number of spheres (>= 2)
+    float g_lo[3], g_cell[3];        // box coordinate = g_lo + q * g_cell
 };
+
+struct NodeBoxes {
+    F3 llo, lhi, rlo, rhi;
+    int left, right;
+};
+__device__ __forceinline__ NodeBoxes load_node(const Bvh &B, int node) {
+    uint4 a = B.nodes[node * 2 + 0], b = B.nodes[node * 2 + 1];
+    auto lo16 = [](uint32_t v) { return (float)(v & 0xffffu); };
+    auto hi16 = [](uint32_t v) { return (float)(v >> 16); };
+    NodeBoxes nb;
+    nb.llo = F3{fmaf(lo16(a.x), B.g_cell[0], B.g_lo[0]), fmaf(hi16(a.x), B.g_cell[1], B.g_lo[1]), fmaf(lo16(a.y), B.g_cell[2], B.g_lo[2])};
+    nb.lhi = F3{fmaf(hi16(a.y), B.g_cell[0], B.g_lo[0]), fmaf(lo16(a.z), B.g_cell[1], B.g_lo[1]), fmaf(hi16(a.z), B.g_cell[2], B.g_lo[2])};
+    nb.rlo = F3{fmaf(lo16(b.x), B.g_cell[0], B.g_lo[0]), fmaf(hi16(b.x), B.g_cell[1], B.g_lo[1]), fmaf(lo16(b.y), B.g_cell[2], B.g_lo[2])};
+    nb.rhi = F3{fmaf(hi16(b.y), B.g_cell[0], B.g_lo[0]), fmaf(lo16(b.z), B.g_cell[1], B.g_lo[1]), fmaf(hi16(b.z), B.g_cell[2], B.g_lo[2])};
+    nb.left = (int)a.w;
+    nb.right = (int)b.w;
+    return nb;
+}
+
 
 constexpr int BVH_STACK = 48;  // entries per lane (LDS); deeper trees raise an error at build time
 
@@ -62,12 +83,11 @@ __device__ __forceinline__ void bvh_closest(const Bvh &B, const RayK &r, float &
     };
     int node = 0, sp = 0;
     for (;;) {
-        float4 n0 = B.nodes[node * 4 + 0], n1 = B.nodes[node * 4 + 1], n2 = B.nodes[node * 4 + 2],
-               n3 = B.nodes[node * 4 + 3];
-        int left = (int)__float_as_uint(n3.x), right = (int)__float_as_uint(n3.y);
+        NodeBoxes nb = load_node(B, node);
+        int left = nb.left, right = nb.right;
         // boxes are tested against best_t inclusively: a sphere that ties must still be visited
-        float tl = box_entry(br, F3{n0.x, n0.y, n0.z}, F3{n0.w, n1.x, n1.y}, best_t);
-        float tr = box_entry(br, F3{n1.z, n1.w, n2.x}, F3{n2.y, n2.z, n2.w}, best_t);
+        float tl = box_entry(br, nb.llo, nb.lhi, best_t);
+        float tr = box_entry(br, nb.rlo, nb.rhi, best_t);
         bool hl = tl < __builtin_inff(), hr = tr < __builtin_inff();
         if (hl && left < 0) {
             leaf(~left);
@@ -100,11 +120,10 @@ __device__ __forceinline__ bool bvh_any(const Bvh &B, const RayK &r, float lim, 
     bool occ = false;
     int node = 0, sp = 0;
     for (;;) {
-        float4 n0 = B.nodes[node * 4 + 0], n1 = B.nodes[node * 4 + 1], n2 = B.nodes[node * 4 + 2],
-               n3 = B.nodes[node * 4 + 3];
-        int left = (int)__float_as_uint(n3.x), right = (int)__float_as_uint(n3.y);
-        bool hl = box_entry(br, F3{n0.x, n0.y, n0.z}, F3{n0.w, n1.x, n1.y}, t_max) < __builtin_inff();
-        bool hr = box_entry(br, F3{n1.z, n1.w, n2.x}, F3{n2.y, n2.z, n2.w}, t_max) < __builtin_inff();
+        NodeBoxes nb = load_node(B, node);
+        int left = nb.left, right = nb.right;
+        bool hl = box_entry(br, nb.llo, nb.lhi, t_max) < __builtin_inff();
+        bool hr = box_entry(br, nb.rlo, nb.rhi, t_max) < __builtin_inff();
         if (hl && left < 0) {
             float t = sphere_t(r, B.sph[~left]);
             ++n_tests;

@@ -6,7 +6,9 @@
 namespace pt {
 
 struct BvhBuffers {
-    float4 *nodes = nullptr;       // (n-1) x 4 float4
+    uint4 *nodes = nullptr;        // (n-1) x 2 uint4: 32-byte nodes, child boxes on a 16-bit grid (pt_bvh.h)
+    float grid_lo[3] = {0, 0, 0};  // box coordinate = grid_lo + q * grid_cell, q = 0..65535
+    float grid_cell[3] = {0, 0, 0};
     float4 *sph_sorted = nullptr;  // n x {c, r*r}, Morton order
     float4 *aux_sorted = nullptr;  // n x {1/r, material, scene order, r}
     uint32_t n = 0;

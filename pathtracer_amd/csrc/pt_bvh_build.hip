@@ -10,6 +10,7 @@
 //   6. pack 64-byte traversal nodes {left box, right box, children}
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>  // rocprim's texture iterator needs ::memset on the host side
 #include <rocprim/rocprim.hpp>
 
@@ -145,17 +146,38 @@ __global__ void k_copy_ready(int n_nodes, const int *__restrict__ src, int *dst)
     if (i < n_nodes) dst[i] = src[i];
 }
 
+// 32-byte node: {L.lo.x | L.lo.y << 16, L.lo.z | L.hi.x << 16, L.hi.y | L.hi.z << 16, left}
+//               {R ... , right}. A box face is stored on a grid of 65536 steps over the root box and moved
+// OUTWARDS by `margin` steps beyond the step that contains it, so that the decoded box (g_lo + q * cell,
+// evaluated in f32 by the traversal) always contains the exact one: boxes may only prune.
+struct Grid {
+    float lo[3], cell[3], inv_cell[3];
+    int margin;
+};
+__device__ __forceinline__ uint32_t q_lo(float v, float g, float inv, int margin) {
+    int q = (int)floorf((v - g) * inv) - margin;
+    return (uint32_t)max(0, min(65535, q));
+}
+__device__ __forceinline__ uint32_t q_hi(float v, float g, float inv, int margin) {
+    int q = (int)ceilf((v - g) * inv) + margin;
+    return (uint32_t)max(0, min(65535, q));
+}
 __global__ void k_pack(int n, const int *__restrict__ left, const int *__restrict__ right, const float4 *__restrict__ lo,
-                       const float4 *__restrict__ hi, float4 *nodes) {
+                       const float4 *__restrict__ hi, Grid G, uint4 *nodes) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     int l = left[i], r = right[i];
     int li = l < 0 ? n - 1 + ~l : l, ri = r < 0 ? n - 1 + ~r : r;
     float4 a = lo[li], b = hi[li], c = lo[ri], d = hi[ri];
-    nodes[i * 4 + 0] = make_float4(a.x, a.y, a.z, b.x);
-    nodes[i * 4 + 1] = make_float4(b.y, b.z, c.x, c.y);
-    nodes[i * 4 + 2] = make_float4(c.z, d.x, d.y, d.z);
-    nodes[i * 4 + 3] = make_float4(__uint_as_float((uint32_t)l), __uint_as_float((uint32_t)r), 0, 0);
+    auto pack = [&](float4 blo, float4 bhi, int child) {
+        uint32_t lx = q_lo(blo.x, G.lo[0], G.inv_cell[0], G.margin), ly = q_lo(blo.y, G.lo[1], G.inv_cell[1], G.margin),
+                 lz = q_lo(blo.z, G.lo[2], G.inv_cell[2], G.margin);
+        uint32_t hx = q_hi(bhi.x, G.lo[0], G.inv_cell[0], G.margin), hy = q_hi(bhi.y, G.lo[1], G.inv_cell[1], G.margin),
+                 hz = q_hi(bhi.z, G.lo[2], G.inv_cell[2], G.margin);
+        return make_uint4(lx | (ly << 16), lz | (hx << 16), hy | (hz << 16), (uint32_t)child);
+    };
+    nodes[i * 2 + 0] = pack(a, b, l);
+    nodes[i * 2 + 1] = pack(c, d, r);
 }
 
 __global__ void k_gather(const float4 *__restrict__ sph, const float4 *__restrict__ aux, const uint32_t *__restrict__ idx,
@@ -199,7 +221,7 @@ hipError_t bvh_build(const float4 *d_sph, const float4 *d_aux, uint32_t n, BvhBu
     BVH_TRY(hipMalloc(&ready_a.p, (size_t)n_nodes * 4));
     BVH_TRY(hipMalloc(&ready_b.p, (size_t)n_nodes * 4));
     BVH_TRY(hipMalloc(&done.p, 4));
-    BVH_TRY(hipMalloc((void **)&out.nodes, (size_t)(N - 1) * 64));
+    BVH_TRY(hipMalloc((void **)&out.nodes, (size_t)(N - 1) * 32));
     BVH_TRY(hipMalloc((void **)&out.sph_sorted, (size_t)n * 16));
     BVH_TRY(hipMalloc((void **)&out.aux_sorted, (size_t)n * 16));
     out.n = n;
@@ -238,8 +260,33 @@ hipError_t bvh_build(const float4 *d_sph, const float4 *d_aux, uint32_t n, BvhBu
         total += d;
         std::swap(ready_a.p, ready_b.p);
     }
+    // quantisation grid over the root box (internal node 0)
+    float4 root_lo, root_hi;
+    BVH_TRY(hipMemcpyAsync(&root_lo, lo.p, 16, hipMemcpyDeviceToHost, st));
+    BVH_TRY(hipMemcpyAsync(&root_hi, hi.p, 16, hipMemcpyDeviceToHost, st));
+    BVH_TRY(hipStreamSynchronize(st));
+    Grid G;
+    const float rl[3] = {root_lo.x, root_lo.y, root_lo.z}, rh[3] = {root_hi.x, root_hi.y, root_hi.z};
+    double max_abs = 0.0, min_cell = INFINITY;
+    for (int k = 0; k < 3; ++k) {
+        double ext = std::max((double)rh[k] - (double)rl[k], 1e-30);
+        double cell = ext / 65000.0;  // the faces keep a few hundred steps of room for the outward margin
+        G.lo[k] = (float)((double)rl[k] - 256.0 * cell);
+        G.cell[k] = (float)cell;
+        G.inv_cell[k] = (float)(1.0 / cell);
+        max_abs = std::max({max_abs, std::fabs((double)rl[k]), std::fabs((double)rh[k])});
+        min_cell = std::min(min_cell, cell);
+    }
+    if (!std::isfinite(max_abs) || !std::isfinite(min_cell)) return hipErrorInvalidValue;
+    // f32 rounding of (v - g) * inv at build time and of g + q * cell at traversal time: a few ulps of the largest
+    // coordinate, expressed in grid steps, plus one
+    G.margin = 1 + (int)std::min(200.0, std::ceil(8.0 * max_abs * 1.2e-7 / min_cell));
+    for (int k = 0; k < 3; ++k) {
+        out.grid_lo[k] = G.lo[k];
+        out.grid_cell[k] = G.cell[k];
+    }
     hipLaunchKernelGGL(k_pack, dim3(g), dim3(bs), 0, st, N, (const int *)left.p, (const int *)right.p, (const float4 *)lo.p,
-                       (const float4 *)hi.p, out.nodes);
+                       (const float4 *)hi.p, G, out.nodes);
     BVH_TRY(hipStreamSynchronize(st));
     BVH_TRY(hipGetLastError());
     if (depth_out) *depth_out = depth;

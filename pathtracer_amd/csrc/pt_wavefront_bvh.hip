@@ -159,12 +159,11 @@ __global__ __launch_bounds__(256) void wfb_traverse(Bvh bvh, WfQueue Q, const fl
         if (!has) continue;
 
         // ---- one node (pt_bvh.h: bvh_closest / bvh_any loop body) ----
-        float4 n0 = bvh.nodes[node * 4 + 0], n1 = bvh.nodes[node * 4 + 1], n2 = bvh.nodes[node * 4 + 2],
-               n3 = bvh.nodes[node * 4 + 3];
-        int left = (int)__float_as_uint(n3.x), right = (int)__float_as_uint(n3.y);
+        NodeBoxes nb = load_node(bvh, node);
+        int left = nb.left, right = nb.right;
         const float bound = ANY ? t_max : best_t;
-        float tl = box_entry(br, F3{n0.x, n0.y, n0.z}, F3{n0.w, n1.x, n1.y}, bound);
-        float tr = box_entry(br, F3{n1.z, n1.w, n2.x}, F3{n2.y, n2.z, n2.w}, bound);
+        float tl = box_entry(br, nb.llo, nb.lhi, bound);
+        float tr = box_entry(br, nb.rlo, nb.rhi, bound);
         bool hl = tl < __builtin_inff(), hr = tr < __builtin_inff();
         bool finished = false;
         if (ANY) {
