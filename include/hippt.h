@@ -186,7 +186,9 @@ int hippt_set_scene(hippt_context *ctx, const hippt_scene *scene);
 /* Launches the trace kernels for samples [sample_begin, sample_begin+count)
  * of every pixel and ADDS the radiance sums into d_accum (device pointer,
  * width*height*3 floats, caller-zeroed). Asynchronous on `stream` (a
- * hipStream_t, NULL = the context's own stream). This is the hot path
+ * hipStream_t, NULL = the context's own stream) for the megakernel variants; the queue
+ * pipelines (HIPPT_FLAG_WAVEFRONT, and LBVH scenes by default) poll their queue
+ * counters and therefore synchronise the stream before returning. This is the hot path
  * (src/renderer.rs:163-182 + 237-353 for every pixel). */
 int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts,
                               float *d_accum, void *stream);

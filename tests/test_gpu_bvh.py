@@ -125,3 +125,23 @@ def test_wavefront_bvh_pipeline_matches_bvh_megakernel(scene20k, oracle):
     mk = hip_renderer.render_accum(s2, 0, 5, seed=2, flags=_abi.FLAG_MEGAKERNEL)
     err = np.abs(full - mk).max(axis=2) / np.maximum(np.abs(mk).max(axis=2), 1e-3 * 5)
     assert np.quantile(err, 0.99) < 1e-4
+
+
+def test_queue_pipeline_edge_cases(scene20k):
+    """LBVH queue pipeline: no lights (black, no shadow rays), one sample, max_depth 1, and the automatic
+    fallback to the megakernel when the path depth does not fit the queue entry's 5-bit depth field."""
+    from pathtracer_amd import _abi, hip_renderer
+    s = scene20k.with_render(40, 24, 2)
+    dark = scene20k.with_render(40, 24, 2)
+    dark.lights = dark.lights[:0]
+    assert (hip_renderer.render_accum(dark) == 0).all()
+    assert (hip_renderer.render_accum(dark, flags=_abi.FLAG_MEGAKERNEL) == 0).all()
+    for kw in (dict(sample_count=1), dict(max_depth=1), dict(max_depth=40)):
+        a = hip_renderer.render_accum(s, seed=3, **kw)
+        b = hip_renderer.render_accum(s, seed=3, flags=_abi.FLAG_MEGAKERNEL, **kw)
+        err = np.abs(a - b).max(axis=2) / np.maximum(np.abs(b).max(axis=2), 2e-3)
+        assert np.isfinite(a).all() and np.quantile(err, 0.99) < 1e-4, kw
+    with pytest.raises(_abi.HipptError):
+        hip_renderer.render_accum(s, flags=_abi.FLAG_WAVEFRONT | _abi.FLAG_MEGAKERNEL)
+    with pytest.raises(_abi.HipptError):
+        hip_renderer.render_accum(s, flags=_abi.FLAG_WAVEFRONT, max_depth=40)
