@@ -119,6 +119,7 @@ typedef struct hippt_scene {
 #define HIPPT_FLAG_NO_BVH 8u     /* force the brute-force object loop        */
 #define HIPPT_FLAG_TABLES_GLOBAL 16u /* read scene tables from global memory
                                         (scalar loads) instead of staging in LDS */
+#define HIPPT_FLAG_NO_SLICES 64u  /* one block renders a tile's whole sample range (no partial-sum slices) */
 #define HIPPT_FLAG_MEGAKERNEL 32u /* force the one-kernel variant (the default for scenes without LBVH) */
 
 typedef struct hippt_options {

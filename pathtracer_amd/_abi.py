@@ -16,6 +16,7 @@ FLAG_BVH = 4
 FLAG_NO_BVH = 8
 FLAG_TABLES_GLOBAL = 16
 FLAG_MEGAKERNEL = 32
+FLAG_NO_SLICES = 64
 
 COUNTER_NAMES = (
     "paths", "extend_rays", "extend_hits", "shadow_rays", "shadow_sphere_tests",

@@ -192,6 +192,8 @@ struct hippt_context {
     size_t wf_ws_bytes = 0;
     pt::BvhBuffers bvh;  // LBVH over the spheres (many-sphere scenes only)
     int bvh_depth = 0;
+    float *slice_buf = nullptr;  // partial sums of sample slices (launch_megakernel)
+    size_t slice_bytes = 0;
     void *chunk_buf = nullptr;  // device staging of the progressive entry points
     size_t chunk_bytes = 0;
     // kernel timing (events on the launch stream)
@@ -233,6 +235,7 @@ int hippt_destroy(hippt_context *ctx) {
     pt::bvh_free(ctx->bvh);
     if (ctx->wf_ws) (void)hipFree(ctx->wf_ws);
     if (ctx->chunk_buf) (void)hipFree(ctx->chunk_buf);
+    if (ctx->slice_buf) (void)hipFree(ctx->slice_buf);
     if (ctx->d_blob) (void)hipFree(ctx->d_blob);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -337,8 +340,24 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
             HIP_TRY(pt::wavefront_render(P, ctx->d_blob, d_accum, ctx->wf_ws, st, nullptr));
         else if (use_bvh)
             HIP_TRY(pt::launch_megakernel_bvh(P, ctx->d_blob, bvh_view(ctx->bvh), stack_entries, d_accum, ctx->d_counters, count, st));
-        else
-            HIP_TRY(pt::launch_megakernel(P, ctx->d_blob, d_accum, ctx->d_counters, count, lds, st));
+        else {
+            // enough blocks for ~16 rounds of the chip's ~1 300 resident blocks, else the last blocks run alone
+            uint64_t tiles = (uint64_t)P.tiles_x * ((P.height + 15u) / 16u);
+            uint32_t slices = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(8, c), (20480 + tiles - 1) / tiles);
+            if (o.flags & HIPPT_FLAG_NO_SLICES) slices = 1;
+            if (slices > 1) {
+                size_t need = (size_t)slices * pixels * 3 * sizeof(float);
+                if (need > ctx->slice_bytes) {
+                    HIP_TRY(hipStreamSynchronize(st));
+                    if (ctx->slice_buf) HIP_TRY(hipFree(ctx->slice_buf));
+                    ctx->slice_buf = nullptr;
+                    ctx->slice_bytes = 0;
+                    HIP_TRY(hipMalloc((void **)&ctx->slice_buf, need));
+                    ctx->slice_bytes = need;
+                }
+            }
+            HIP_TRY(pt::launch_megakernel(P, ctx->d_blob, d_accum, ctx->d_counters, count, lds, st, ctx->slice_buf, slices));
+        }
         HIP_TRY(hipEventRecord(ev.second, st));
         s0 += c;
         cnt -= c;

@@ -38,7 +38,7 @@ struct WaveLds {
 template <class Tbl, bool COUNT, bool BVH = false>
 __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x_own, uint32_t y_own, bool in_image,
                                             float *__restrict__ accum, unsigned long long *__restrict__ counters,
-                                            WaveLds *wl, Bvh bvh = Bvh{}, uint32_t *stack = nullptr) {
+                                            WaveLds *wl, Bvh bvh = Bvh{}, uint32_t *stack = nullptr, bool overwrite = false) {
     Tracer<Tbl, COUNT, BVH> tr(P, tbl, bvh, stack);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t pixel = y_own * P.width + x_own;
@@ -194,9 +194,15 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
     __builtin_amdgcn_wave_barrier();
     if (in_image) {
         float *px = accum + (size_t)pixel * 3;
-        px[0] += wl->acc[lane * 3 + 0];
-        px[1] += wl->acc[lane * 3 + 1];
-        px[2] += wl->acc[lane * 3 + 2];
+        if (overwrite) {  // a slice of the launch's sample range: partial sums, added up by pt_add_partials
+            px[0] = wl->acc[lane * 3 + 0];
+            px[1] = wl->acc[lane * 3 + 1];
+            px[2] = wl->acc[lane * 3 + 2];
+        } else {
+            px[0] += wl->acc[lane * 3 + 0];
+            px[1] += wl->acc[lane * 3 + 1];
+            px[2] += wl->acc[lane * 3 + 2];
+        }
     }
     if (COUNT) {
         // wave-reduce then one atomic per wave and counter
@@ -206,6 +212,19 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
             if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&counters[k], (unsigned long long)v);
         }
     }
+}
+
+// A launch may cut its sample range into gridDim.y slices (launch_megakernel): block (tile, j) renders slice j of the
+// tile's samples and writes partial sums to slice j of `accum` (then a partial-sum buffer). With ~8 000 tiles at
+// 1080p and ~1 300 resident blocks a whole-range block lasts a sixth of the launch and the last ones run on a
+// half-empty chip; slices shorten that tail.
+__device__ __forceinline__ float *sample_slice(Params &P, float *accum) {
+    const uint32_t J = gridDim.y, j = blockIdx.y;
+    if (J == 1u) return accum;
+    const uint32_t base = P.sample_count / J, rem = P.sample_count % J;
+    P.sample_begin += j * base + min(j, rem);
+    P.sample_count = base + (j < rem ? 1u : 0u);
+    return accum + (size_t)j * P.width * P.height * 3;
 }
 
 // Scene tables in LDS (north-star layout).
@@ -223,7 +242,8 @@ __global__ __launch_bounds__(256, PT_MIN_WAVES) void pt_megakernel_lds(Params P,
     lane_pixel(P, x, y);
     bool in_image = (x < P.width) & (y < P.height);
     __shared__ WaveLds s_wl[4];
-    trace_pixel<TblLds, COUNT>(P, TblLds{s_tbl}, x, y, in_image, accum, counters, &s_wl[threadIdx.x >> 6]);
+    float *out = sample_slice(P, accum);
+    trace_pixel<TblLds, COUNT>(P, TblLds{s_tbl}, x, y, in_image, out, counters, &s_wl[threadIdx.x >> 6], Bvh{}, nullptr, gridDim.y > 1u);
 }
 
 // Scene tables read from global memory (scenes too large for LDS).
@@ -235,7 +255,8 @@ __global__ __launch_bounds__(256) void pt_megakernel_global(Params P, const floa
     lane_pixel(P, x, y);
     bool in_image = (x < P.width) & (y < P.height);
     __shared__ WaveLds s_wl[4];
-    trace_pixel<TblGlobal, COUNT>(P, TblGlobal{blob}, x, y, in_image, accum, counters, &s_wl[threadIdx.x >> 6]);
+    float *out = sample_slice(P, accum);
+    trace_pixel<TblGlobal, COUNT>(P, TblGlobal{blob}, x, y, in_image, out, counters, &s_wl[threadIdx.x >> 6], Bvh{}, nullptr, gridDim.y > 1u);
 }
 
 // Many-sphere scenes: spheres through the LBVH, everything else from global tables.
@@ -431,21 +452,38 @@ __global__ void pt_unit_rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint
 // ---- launchers (host) -------------------------------------------------------------
 static inline unsigned grid_for(uint32_t n, unsigned bs = 256) { return (n + bs - 1) / bs; }
 
+__global__ __launch_bounds__(256) void pt_add_partials(float *__restrict__ accum, const float *__restrict__ partial,
+                                                       uint32_t slices, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float v = partial[i];
+    for (uint32_t j = 1; j < slices; ++j) v += partial[(size_t)j * n + i];  // fixed order: deterministic
+    accum[i] += v;
+}
+
+// slices > 1: the sample range is cut into `slices` parts rendered by separate blocks into `partial`
+// (slices x width*height*3 floats), which are then added to accum in a fixed order.
 hipError_t launch_megakernel(const Params &P, const float4 *blob, float *accum, unsigned long long *counters,
-                             bool count, bool lds, hipStream_t st) {
+                             bool count, bool lds, hipStream_t st, float *partial, uint32_t slices) {
     uint32_t tiles_y = (P.height + 15u) / 16u;
-    dim3 grid(P.tiles_x * tiles_y), block(256);
+    if (slices < 1u || !partial) slices = 1u;
+    dim3 grid(P.tiles_x * tiles_y, slices), block(256);
+    float *out = slices > 1u ? partial : accum;
     size_t shmem = (size_t)P.blob_f4 * sizeof(float4);
     if (lds) {
         if (count)
-            hipLaunchKernelGGL(pt_megakernel_lds<true>, grid, block, shmem, st, P, blob, accum, counters);
+            hipLaunchKernelGGL(pt_megakernel_lds<true>, grid, block, shmem, st, P, blob, out, counters);
         else
-            hipLaunchKernelGGL(pt_megakernel_lds<false>, grid, block, shmem, st, P, blob, accum, counters);
+            hipLaunchKernelGGL(pt_megakernel_lds<false>, grid, block, shmem, st, P, blob, out, counters);
     } else {
         if (count)
-            hipLaunchKernelGGL(pt_megakernel_global<true>, grid, block, 0, st, P, blob, accum, counters);
+            hipLaunchKernelGGL(pt_megakernel_global<true>, grid, block, 0, st, P, blob, out, counters);
         else
-            hipLaunchKernelGGL(pt_megakernel_global<false>, grid, block, 0, st, P, blob, accum, counters);
+            hipLaunchKernelGGL(pt_megakernel_global<false>, grid, block, 0, st, P, blob, out, counters);
+    }
+    if (slices > 1u) {
+        size_t n = (size_t)P.width * P.height * 3;
+        hipLaunchKernelGGL(pt_add_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, accum, (const float *)partial, slices, n);
     }
     return hipGetLastError();
 }

@@ -78,6 +78,19 @@ def test_tables_global_variant_matches_lds(oracle):
     _compare(a, b, 16)
 
 
+def test_sample_slices_change_only_the_summation_order():
+    """A launch cuts its sample range into slices rendered by separate blocks (partial sums added in a fixed
+    order): same paths, so the same image up to f32 summation order, and still deterministic."""
+    from pathtracer_amd import Scene, hip_renderer, _abi
+    for w, h, spp in ((64, 48, 37), (1920, 1080, 5)):
+        s = Scene.load(os.path.join(ROOT, "scenes", "scene.example.json"), w, h, spp)
+        a, ca = hip_renderer.render_accum(s, seed=4, counters=True)
+        b, cb = hip_renderer.render_accum(s, seed=4, counters=True, flags=_abi.FLAG_NO_SLICES)
+        assert ca == cb
+        assert np.allclose(a, b, rtol=3e-6, atol=1e-6)
+        assert np.array_equal(a, hip_renderer.render_accum(s, seed=4))
+
+
 def test_sample_ranges_add_up():
     """Sample-range split (multi-GPU partitioning): [0,24) + [24,64) == [0,64) up to f32 summation order."""
     from pathtracer_amd import Scene, hip_renderer
