@@ -341,9 +341,9 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
         else if (use_bvh)
             HIP_TRY(pt::launch_megakernel_bvh(P, ctx->d_blob, bvh_view(ctx->bvh), stack_entries, d_accum, ctx->d_counters, count, st));
         else {
-            // enough blocks for ~16 rounds of the chip's ~1 300 resident blocks, else the last blocks run alone
+            // enough blocks for ~50 rounds of the chip's ~1 300 resident blocks (measured: 3 slices +3.4 %, 8 slices +4.6 %, 16 no more)
             uint64_t tiles = (uint64_t)P.tiles_x * ((P.height + 15u) / 16u);
-            uint32_t slices = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(8, c), (20480 + tiles - 1) / tiles);
+            uint32_t slices = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(8, c), (65280 + tiles - 1) / tiles);
             if (o.flags & HIPPT_FLAG_NO_SLICES) slices = 1;
             if (slices > 1) {
                 size_t need = (size_t)slices * pixels * 3 * sizeof(float);
