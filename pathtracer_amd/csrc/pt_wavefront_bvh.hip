@@ -363,9 +363,9 @@ __global__ __launch_bounds__(256) void wfb_nee_gen(Params P, const float4 *__res
         for (uint32_t li = 0; li < P.n_light; ++li) {
             uint32_t o = P.light_off + li * LIGHT_F4;
             float4 l0 = tbl.ld(o), l1 = tbl.ld(o + 1), l2 = tbl.ld(o + 2), l4 = tbl.ld(o + 4);
-#pragma unroll 1
+            bool want[4] = {false, false, false, false};
+#pragma unroll
             for (uint32_t s = 0; s < 4; ++s) {
-                bool want = false;
                 const uint32_t k = li * 4 + s;
                 if (act) {
                     float e1 = rng.gen() - 0.5f;
@@ -381,13 +381,35 @@ __global__ __launch_bounds__(256) void wfb_nee_gen(Params P, const float4 *__res
                     sp5[2 * cap] = l.z;
                     sp5[3 * cap] = (dist2 * inv) * 0.99949987493746f;  // |lvec| sqrt(0.999)
                     sp5[4 * cap] = inv * inv;
-                    want = (dot(nn, l) > 0.0f) & (-dot(l, f3(l4)) > 0.0f);
-                    if (!want) occ[(size_t)k * cap + qi] = 1;
+                    want[s] = (dot(nn, l) > 0.0f) & (-dot(l, f3(l4)) > 0.0f);
+                    if (!want[s]) occ[(size_t)k * cap + qi] = 1;
                 }
-                uint32_t pos, unused;
-                queue_reserve2(want, ray_count, pos, false, nullptr, unused, s_cnt, s_base);
-                if (want) ray_list[pos] = k * (uint32_t)cap + qi;
             }
+            // one reservation per block and light for the 4 samples: list order (wave, sample, lane)
+            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            unsigned long long m[4];
+            uint32_t wave_tot = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                m[s] = __ballot(want[s]);
+                wave_tot += (uint32_t)__popcll(m[s]);
+            }
+            if (lane == 0) s_cnt[0][wave] = wave_tot;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t tot = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+                s_base[0] = tot ? atomicAdd(ray_count, tot) : 0u;
+            }
+            __syncthreads();
+            uint32_t off = s_base[0];
+            for (uint32_t w = 0; w < wave; ++w) off += s_cnt[0][w];
+#pragma unroll
+            for (uint32_t s = 0; s < 4; ++s) {
+                if (want[s]) ray_list[off + (uint32_t)__popcll(m[s] & below)] = (li * 4 + s) * (uint32_t)cap + qi;
+                off += (uint32_t)__popcll(m[s]);
+            }
+            __syncthreads();  // s_cnt / s_base are reused by the next light
         }
         if (act) {
             Qshade.stu(U_RNG0, qi, rng.s0);
