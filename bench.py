@@ -23,10 +23,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU (packed f32)
-# HBM bytes of one megakernel launch at 1920x1080 from the PMC passes in profiles/r01_megakernel_v5_traffic_pmc.txt
-# (FETCH_SIZE 18214 KB, doubled per the gfx950 correction, + WRITE_SIZE 28289.5 KB; the launch reads and writes the
-# 24.9 MB accumulator once, whatever the sample count). Counters cannot be read inside this process.
-MEGAKERNEL_1080P_TRAFFIC_BYTES = int((2 * 18214.0 + 28289.5) * 1024)
+# HBM bytes of one megakernel launch at 1920x1080 from the PMC passes in profiles/r01_megakernel_v6_traffic_pmc.txt
+# (FETCH_SIZE 2035.6 KB, doubled per the gfx950 correction, + WRITE_SIZE 203798 KB; the launch writes 8 sample
+# slices of partial sums, 24.9 MB each, whatever the sample count; pt_add_partials then reads them once). Counters cannot be read inside this process.
+MEGAKERNEL_1080P_TRAFFIC_BYTES = int((2 * 2035.6 + 203798.0) * 1024)
 
 
 def cpu_baseline(threads):
@@ -167,7 +167,7 @@ def main():
                          "note": "algorithmic FLOPs (SURVEY §8d event costs x device event counters of this step) / "
                                  "mean trace-kernel duration from HIP events on the launch stream; the path is "
                                  "VALU-bound (no MFMA); traffic = HBM bytes per launch from the committed PMC passes "
-                                 "(profiles/r01_megakernel_v5_traffic_pmc.txt), ~32 B per pixel per launch"},
+                                 "(profiles/r01_megakernel_v6_traffic_pmc.txt), ~103 B per pixel per launch"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
