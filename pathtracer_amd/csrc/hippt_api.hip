@@ -77,18 +77,8 @@ int pack_scene(const hippt_scene *sc, PackedScene &out) {
         return hippt_set_error(HIPPT_ERR_INVALID, "NULL table with non-zero count");
     pt::Params &P = out.P;
     const hippt_camera &c = sc->camera;
-    std::memcpy(P.cam_pos, c.pos, 12);
-    std::memcpy(P.cam_right, c.right, 12);
-    std::memcpy(P.cam_up, c.up, 12);
-    std::memcpy(P.cam_fwd, c.forward, 12);
-    P.aspect = c.aspect;
-    P.scale = c.scale;
-    P.aperture = c.aperture;
-    P.focus = c.focus;
     P.width = sc->width;
     P.height = sc->height;
-    P.inv_w = 1.0f / (float)sc->width;
-    P.inv_h = 1.0f / (float)sc->height;
     P.n_sph = sc->n_spheres;
     P.n_pl = sc->n_planes;
     P.n_mat = sc->n_materials;
@@ -98,9 +88,18 @@ int pack_scene(const hippt_scene *sc, PackedScene &out) {
     P.aux_off = P.pl_off + P.n_pl * 3u;
     P.mat_off = P.aux_off + P.n_sph + P.n_pl;
     P.light_off = P.mat_off + sc->n_materials * pt::MAT_F4;
-    P.blob_f4 = P.light_off + sc->n_lights * pt::LIGHT_F4;
+    P.cam_off = P.light_off + sc->n_lights * pt::LIGHT_F4;
+    P.blob_f4 = P.cam_off + pt::CAM_F4;
     P.tiles_x = (sc->width + 15u) / 16u;
-    out.blob.assign(P.blob_f4 ? P.blob_f4 : 1, mk4(0, 0, 0, 0));
+    out.blob.assign(P.blob_f4, mk4(0, 0, 0, 0));
+    {
+        float4 *q = &out.blob[P.cam_off];
+        q[0] = mk4(c.pos[0], c.pos[1], c.pos[2], c.aspect);
+        q[1] = mk4(c.right[0], c.right[1], c.right[2], c.scale);
+        q[2] = mk4(c.up[0], c.up[1], c.up[2], c.aperture);
+        q[3] = mk4(c.forward[0], c.forward[1], c.forward[2], c.focus);
+        q[4] = mk4(1.0f / (float)sc->width, 1.0f / (float)sc->height, 0, 0);
+    }
 
     // Each table is written in ascending scene order, so that strict '<' inside a table keeps
     // the first minimum (renderer.rs:359-361).
@@ -684,12 +683,13 @@ int hippt_test_camera_ray(const hippt_scene *scene, uint32_t n, const uint32_t *
     PackedScene ps;
     rc = pack_scene(scene, ps);
     if (rc) return rc;
-    DevBuf a, b, o1, o2;
+    DevBuf blob, a, b, o1, o2;
+    UP(blob, ps.blob.data(), ps.blob.size() * 16);
     UP(a, xy, (size_t)n * 8);
     UP(b, u4, (size_t)n * 16);
     HIP_TRY(o1.alloc((size_t)n * 12));
     HIP_TRY(o2.alloc((size_t)n * 12));
-    if (n) HIP_TRY(pt::launch_unit_camera(ps.P, n, a.as<uint32_t>(), b.as<float>(), o1.as<float>(), o2.as<float>(), nullptr));
+    if (n) HIP_TRY(pt::launch_unit_camera(ps.P, blob.as<float4>(), n, a.as<uint32_t>(), b.as<float>(), o1.as<float>(), o2.as<float>(), nullptr));
     DOWN(out_ro, o1, (size_t)n * 12);
     DOWN(out_rd, o2, (size_t)n * 12);
     return HIPPT_OK;

@@ -20,19 +20,16 @@ namespace pt {
 //   aux      : (n_sph + n_pl) x 1  {1/r, material, scene order, 0}
 //   materials: n_mat x 2  {r,g,b,metallic} {roughness,ior,density,anisotropy}
 //   lights   : n_light x 5 {pos,area} {u,0} {v,0} {intensity,0} {normal,0}
+//   camera   : 5  {pos,aspect} {right,scale} {up,aperture} {forward,focus} {1/width,1/height,0,0}
+//              (in the blob, not in Params: read once per path, and 22 fewer SGPRs live across the trace loop)
 constexpr int MAT_F4 = 2;
 constexpr int LIGHT_F4 = 5;
+constexpr int CAM_F4 = 5;
 
 struct Params {
-    float cam_pos[3];
-    float cam_right[3];
-    float cam_up[3];
-    float cam_fwd[3];
-    float aspect, scale, aperture, focus;
     uint32_t width, height;
-    float inv_w, inv_h;
     uint32_t n_sph, n_pl, n_mat, n_light;
-    uint32_t sph_off, pl_off, aux_off, mat_off, light_off;  // float4 offsets into the blob
+    uint32_t sph_off, pl_off, aux_off, mat_off, light_off, cam_off;  // float4 offsets into the blob
     uint32_t blob_f4;             // blob size in float4
     uint32_t sample_begin, sample_count, max_depth, seed;
     uint32_t tiles_x;             // 16x16 pixel tiles per row
@@ -310,54 +307,110 @@ __device__ __forceinline__ float sub_unfused(float a, float b) {
 //           hit - p = (x - p) + l (t + eps)            =>  d.u' = Du + (t + eps) l.u'
 // which is the arithmetic of sphere.rs:26-33 / plane.rs:25-52 re-associated (differences
 // ~1e-7 relative in t; they can only move an occlusion decision that sits on its threshold).
-template <class Tbl, int NS, bool COUNT>
+// One sphere row against the NS rays: hit[s] = the ray is blocked by this sphere.
+template <int NS>
+__device__ __forceinline__ void sphere_shadow_row(float4 c, F3 x, float eps, const F3 (&l)[NS], const float (&q)[NS],
+                                                  bool (&hit)[NS]) {
+    F3 X = x - f3(c);
+    float C0 = fmaf(X.z, X.z, fmaf(X.y, X.y, fmaf(X.x, X.x, -c.w)));  // X.X - r^2
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        // the discriminant does not depend on where along the ray the origin sits: with o = x + eps l,
+        // (oc.l)^2 - (oc.oc - r^2) = (X.l)^2 - (X.X - r^2); the near root from x is t0 = -X.l - sqrt(disc)
+        float d1 = dot(X, l[s]);
+        float t0 = -d1 - fsqrt(fmaf(d1, d1, -C0));
+        hit[s] = fabsf(t0 - q[s]) < q[s] - eps;  // NaN: false
+    }
+}
+// One plane (3 rows) against the NS rays.
+template <int NS>
+__device__ __forceinline__ void plane_shadow_row(float4 q0, float4 q1, float4 q2, F3 x, float eps, const F3 (&l)[NS],
+                                                 const float (&q)[NS], bool (&hit)[NS]) {
+    F3 n = F3{q0.w, q1.x, q1.y}, u = F3{q1.z, q1.w, q2.x}, v = F3{q2.y, q2.z, q2.w};
+    F3 Xp = x - f3(q0);
+    float Dn = -dot(Xp, n), Du = dot(Xp, u), Dv = dot(Xp, v);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float denom = dot(n, l[s]);
+        float tp = Dn * rcp(denom);
+        float du = fmaf(tp, dot(l[s], u), Du);
+        float dv = fmaf(tp, dot(l[s], v), Dv);
+        // 1e-4 < t < tmax with t = tp - eps:  |tp - 5e-5 - q| < q - eps - 5e-5
+        float dt = sub_unfused(tp, 5e-5f) - q[s];
+        bool ok = (fabsf(denom) >= 1e-6f) & (fmaxf(fabsf(du), fabsf(dv)) <= 1.0f);
+        hit[s] = ok & (fabsf(dt) < q[s] - (eps + 5e-5f));
+    }
+}
+// q = eps + tmax/2: with t = t0 - eps (t0 measured from x), 0 < t < tmax  <=>  |t0 - q| < q - eps
+template <int NS>
+__device__ __forceinline__ void shadow_mid(float eps, const float (&tmax)[NS], float (&q)[NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) q[s] = fmaf(0.5f, tmax[s], eps);
+}
+// One object (wave-uniform index: spheres first, then planes) against the NS rays, same arithmetic as the loops below.
+template <class Tbl, int NS>
+__device__ __forceinline__ void object_shadow(const Tbl &tbl, const Params &P, uint32_t obj, F3 x, float eps,
+                                              const F3 (&l)[NS], const float (&tmax)[NS], bool (&hit)[NS]) {
+    float q[NS];
+    shadow_mid<NS>(eps, tmax, q);
+    if (obj < P.n_sph) {
+        sphere_shadow_row<NS>(tbl.ld(P.sph_off + obj), x, eps, l, q, hit);
+    } else {
+        uint32_t o = P.pl_off + (obj - P.n_sph) * 3u;
+        plane_shadow_row<NS>(tbl.ld(o), tbl.ld(o + 1), tbl.ld(o + 2), x, eps, l, q, hit);
+    }
+}
+
+// LEARN: also report the object that blocks ALL NS rays of the most lanes (`dominant`, an object index as
+// object_shadow takes it, and on how many of the calling lanes, `dominant_lanes`); both are wave-uniform and
+// formed with scalar instructions from the compare masks.
+template <class Tbl, int NS, bool COUNT, bool LEARN = false>
 __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, F3 x, float eps, const F3 (&l)[NS],
                                                const float (&tmax)[NS], bool (&occ)[NS], uint32_t &n_sph_tests,
-                                               uint32_t &n_pl_tests, bool spheres = true) {
+                                               uint32_t &n_pl_tests, bool spheres = true, uint32_t *dominant = nullptr,
+                                               uint32_t *dominant_lanes = nullptr) {
     const uint32_t n_sph = spheres ? P.n_sph : 0u;  // false: the caller has tested the spheres (BVH) and set occ[]
     if (spheres) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) occ[s] = false;
     }
-    // q = eps + tmax/2: with t = t0 - eps (t0 measured from x), 0 < t < tmax  <=>  |t0 - q| < q - eps
     float q[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) q[s] = fmaf(0.5f, tmax[s], eps);
-#pragma unroll 1
-    for (uint32_t i = 0; i < n_sph; ++i) {
-        float4 c = tbl.ld(P.sph_off + i);
-        F3 X = x - f3(c);
-        float C0 = fmaf(X.z, X.z, fmaf(X.y, X.y, fmaf(X.x, X.x, -c.w)));  // X.X - r^2
+    shadow_mid<NS>(eps, tmax, q);
+    uint32_t best = 0xffffffffu, best_lanes = 0;
+    auto fold = [&](const bool (&hit)[NS], uint32_t obj) {
+        bool all = true;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            // the discriminant does not depend on where along the ray the origin sits: with o = x + eps l,
-            // (oc.l)^2 - (oc.oc - r^2) = (X.l)^2 - (X.X - r^2); the near root from x is t0 = -X.l - sqrt(disc)
-            float d1 = dot(X, l[s]);
-            float t0 = -d1 - fsqrt(fmaf(d1, d1, -C0));
-            occ[s] = occ[s] | (fabsf(t0 - q[s]) < q[s] - eps);  // NaN: false
+            occ[s] = occ[s] | hit[s];
+            all = all & hit[s];
         }
+        if (LEARN) {
+            uint32_t c = (uint32_t)__popcll(__ballot(all));
+            if (c > best_lanes) {
+                best_lanes = c;
+                best = obj;
+            }
+        }
+    };
+#pragma unroll 1
+    for (uint32_t i = 0; i < n_sph; ++i) {
+        bool hit[NS];
+        sphere_shadow_row<NS>(tbl.ld(P.sph_off + i), x, eps, l, q, hit);
+        fold(hit, i);
     }
     if (COUNT) n_sph_tests += NS * n_sph;
 #pragma unroll 1
     for (uint32_t j = 0; j < P.n_pl; ++j) {
         uint32_t o = P.pl_off + j * 3u;
-        float4 q0 = tbl.ld(o), q1 = tbl.ld(o + 1), q2 = tbl.ld(o + 2);
-        F3 n = F3{q0.w, q1.x, q1.y}, u = F3{q1.z, q1.w, q2.x}, v = F3{q2.y, q2.z, q2.w};
-        F3 Xp = x - f3(q0);
-        float Dn = -dot(Xp, n), Du = dot(Xp, u), Dv = dot(Xp, v);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            float denom = dot(n, l[s]);
-            float tp = Dn * rcp(denom);
-            float du = fmaf(tp, dot(l[s], u), Du);
-            float dv = fmaf(tp, dot(l[s], v), Dv);
-            // 1e-4 < t < tmax with t = tp - eps:  |tp - 5e-5 - q| < q - eps - 5e-5
-            float dt = sub_unfused(tp, 5e-5f) - q[s];
-            bool ok = (fabsf(denom) >= 1e-6f) & (fmaxf(fabsf(du), fabsf(dv)) <= 1.0f);
-            occ[s] = occ[s] | (ok & (fabsf(dt) < q[s] - (eps + 5e-5f)));
-        }
+        bool hit[NS];
+        plane_shadow_row<NS>(tbl.ld(o), tbl.ld(o + 1), tbl.ld(o + 2), x, eps, l, q, hit);
+        fold(hit, P.n_sph + j);
     }
     if (COUNT) n_pl_tests += NS * P.n_pl;
+    if (LEARN) {
+        *dominant = best;
+        *dominant_lanes = best_lanes;
+    }
 }
 
 // ---- BSDF -------------------------------------------------------------------------
@@ -517,18 +570,19 @@ __device__ __forceinline__ F3 nee_eval(const ShadeK &s, F3 l, float inv_dist2, F
 }
 
 // renderer.rs:170-178 + algebra.rs:67-73
-__device__ __forceinline__ void camera_ray(const Params &P, uint32_t x, uint32_t y, float jx, float jy, float ds,
-                                           float dt, F3 &ro, F3 &rd) {
-    F3 right = F3{P.cam_right[0], P.cam_right[1], P.cam_right[2]};
-    F3 up = F3{P.cam_up[0], P.cam_up[1], P.cam_up[2]};
-    F3 fwd = F3{P.cam_fwd[0], P.cam_fwd[1], P.cam_fwd[2]};
-    F3 pos = F3{P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]};
-    float u = (((float)x + jx) * P.inv_w - 0.5f) * 2.0f * P.aspect * P.scale;
-    float v = -(((float)y + jy) * P.inv_h - 0.5f) * 2.0f * P.scale;
+template <class Tbl>
+__device__ __forceinline__ void camera_ray(const Tbl &tbl, const Params &P, uint32_t x, uint32_t y, float jx, float jy,
+                                           float ds, float dt, F3 &ro, F3 &rd) {
+    const float4 c0 = tbl.ld(P.cam_off), c1 = tbl.ld(P.cam_off + 1), c2 = tbl.ld(P.cam_off + 2);
+    const float4 c3 = tbl.ld(P.cam_off + 3), c4 = tbl.ld(P.cam_off + 4);
+    F3 pos = f3(c0), right = f3(c1), up = f3(c2), fwd = f3(c3);
+    const float aspect = c0.w, scale = c1.w, aperture = c2.w, focus = c3.w;
+    float u = (((float)x + jx) * c4.x - 0.5f) * 2.0f * aspect * scale;
+    float v = -(((float)y + jy) * c4.y - 0.5f) * 2.0f * scale;
     F3 rd0 = normalize(right * u + up * v + fwd);
-    float rad = P.aperture * fsqrt(dt);
+    float rad = aperture * fsqrt(dt);
     float dx = rad * cos2pi(ds), dy = rad * sin2pi(ds);
-    F3 focal = madd(pos, rd0, P.focus);
+    F3 focal = madd(pos, rd0, focus);
     ro = pos + right * dx + up * dy;
     rd = normalize(focal - ro);
 }

@@ -26,6 +26,7 @@ __device__ __forceinline__ void lane_pixel(const Params &P, uint32_t &x, uint32_
 struct WaveLds {
     float acc[64 * 3];
     uint32_t mix[64];
+    NeeShare nee;  // Tracer::direct_light_shared
 };
 
 // One wave renders the sample_count samples of its 8x8 pixels as a POOL of 64 * sample_count work items
@@ -40,6 +41,9 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
                                             float *__restrict__ accum, unsigned long long *__restrict__ counters,
                                             WaveLds *wl, Bvh bvh = Bvh{}, uint32_t *stack = nullptr, bool overwrite = false) {
     Tracer<Tbl, COUNT, BVH> tr(P, tbl, bvh, stack);
+#ifdef PT_NEE_DIAG
+    tr.diag = counters;
+#endif
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t pixel = y_own * P.width + x_own;
     const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
@@ -48,6 +52,8 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
     wl->acc[lane * 3 + 0] = 0.0f;
     wl->acc[lane * 3 + 1] = 0.0f;
     wl->acc[lane * 3 + 2] = 0.0f;
+    if (lane < kHintLights) wl->nee.hint[lane] = kNoHint;
+    if (lane == 0u) wl->nee.pending = 0u;
     __builtin_amdgcn_wave_barrier();
 
     uint32_t cur_lane = 0, cur_sample = 0;  // wave-uniform cursor into the item sequence
@@ -78,7 +84,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
                     // renderer.rs:170-178: new camera path
                     rng.seed(seed_mixed, wl->mix[my_pl], P.sample_begin + my_sample);
                     float jx = rng.gen(), jy = rng.gen(), ds = rng.gen(), dt = rng.gen();
-                    camera_ray(P, px, py, jx, jy, ds, dt, ro, rd);
+                    camera_ray(tbl, P, px, py, jx, jy, ds, dt, ro, rd);
                     T = F3{1, 1, 1};
                     psum = F3{0.0f, 0.0f, 0.0f};
                     depth = 0;
@@ -141,9 +147,13 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
             }
         }
 
+        constexpr bool kSharedNee = !COUNT && !BVH;
+        ShadeK sk;
+        F3 D;
+        if (kind != 0) sk = make_shade(n, -rd, m);
+        if constexpr (kSharedNee) D = tr.direct_light_shared(kind != 0, x, sk, rng, T, my_pl, &wl->nee, wl->acc);
         if (kind != 0) {
-            ShadeK sk = make_shade(n, -rd, m);
-            F3 D = tr.direct_light(x, sk, rng);
+            if constexpr (!kSharedNee) D = tr.direct_light(x, sk, rng);
             psum = psum + T * D;  // :285 / :325
             if (kind == 2) {
                 float ct = sample_phase_function(m.aniso, rng.gen());
@@ -191,6 +201,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
         }
     }
 
+    if constexpr (!COUNT && !BVH) tr.flush_pairs(&wl->nee, wl->acc);
     __builtin_amdgcn_wave_barrier();
     if (in_image) {
         float *px = accum + (size_t)pixel * 3;
@@ -425,12 +436,12 @@ __global__ void pt_unit_hg(uint32_t n, const float *rd, const float *g, const fl
     out4[4 * i + 3] = d.z;
 }
 
-__global__ void pt_unit_camera(Params P, uint32_t n, const uint32_t *xy, const float *u4, float *out_ro,
-                               float *out_rd) {
+__global__ void pt_unit_camera(Params P, const float4 *__restrict__ blob, uint32_t n, const uint32_t *xy, const float *u4,
+                               float *out_ro, float *out_rd) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     F3 ro, rd;
-    camera_ray(P, xy[2 * i], xy[2 * i + 1], u4[4 * i], u4[4 * i + 1], u4[4 * i + 2], u4[4 * i + 3], ro, rd);
+    camera_ray(TblGlobal{blob}, P, xy[2 * i], xy[2 * i + 1], u4[4 * i], u4[4 * i + 1], u4[4 * i + 2], u4[4 * i + 3], ro, rd);
     st3(out_ro, i, ro);
     st3(out_rd, i, rd);
 }
@@ -558,9 +569,9 @@ hipError_t launch_unit_hg(uint32_t n, const float *rd, const float *g, const flo
     hipLaunchKernelGGL(pt_unit_hg, dim3(grid_for(n)), dim3(256), 0, st, n, rd, g, u_hg, u_phi, out4);
     return hipGetLastError();
 }
-hipError_t launch_unit_camera(const Params &P, uint32_t n, const uint32_t *xy, const float *u4, float *out_ro,
+hipError_t launch_unit_camera(const Params &P, const float4 *blob, uint32_t n, const uint32_t *xy, const float *u4, float *out_ro,
                               float *out_rd, hipStream_t st) {
-    hipLaunchKernelGGL(pt_unit_camera, dim3(grid_for(n)), dim3(256), 0, st, P, n, xy, u4, out_ro, out_rd);
+    hipLaunchKernelGGL(pt_unit_camera, dim3(grid_for(n)), dim3(256), 0, st, P, blob, n, xy, u4, out_ro, out_rd);
     return hipGetLastError();
 }
 hipError_t launch_unit_tonemap(uint32_t n3, const float *rgb, uint8_t *out, hipStream_t st) {

@@ -7,6 +7,27 @@
 
 namespace pt {
 
+// Per-wave LDS of Tracer::direct_light_shared.
+constexpr uint32_t kHintLights = 8;  // lights that keep a remembered occluder
+constexpr uint32_t kNoHint = 0xffffffffu;
+constexpr uint32_t kPairCap = 128;   // pending shadow rays: < 64 left over + at most 64 new ones per light
+constexpr uint32_t kPairBatch = 64;
+constexpr uint32_t kPairWords = 11;  // x, l, tmax, the radiance the ray carries if it arrives, pixel slot
+struct NeeShare {
+    uint32_t hint[kHintLights];  // per light: the object that last blocked all 4 samples of most lanes
+    uint32_t pending;            // rays in the list (copy of Tracer::pending for the lanes that leave the loop last)
+    float pair[kPairWords * kPairCap];  // word-major list of shadow rays not yet tested against the whole scene
+};
+
+__device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // BVH = true: spheres through the LBVH (pt_bvh.h), planes through the table loops.
 template <class Tbl, bool COUNT, bool BVH>
 struct Tracer {
@@ -15,6 +36,9 @@ struct Tracer {
     Bvh bvh;
     uint32_t *stack;  // this lane's LDS traversal stack column (BVH only), stride 256
     uint32_t cnt[HIPPT_N_COUNTERS];
+#ifdef PT_NEE_DIAG
+    unsigned long long *diag = nullptr;
+#endif
 
     __device__ __forceinline__ Tracer(const Params &p, Tbl t, Bvh b, uint32_t *stk) : P(p), tbl(t), bvh(b), stack(stk) {
         if (COUNT)
@@ -100,6 +124,148 @@ struct Tracer {
                 }
             }
             total = madd(total, contrib, 0.25f);  // :82
+        }
+        return total;
+    }
+
+    // direct_light for a whole wave (every lane of the wave that is still in the trace loop calls it; `nee` =
+    // this lane has a vertex to light). Same samples and same tests as direct_light, in a different order: on
+    // scenes like scene.example most shading points have all 4 samples of one light blocked by the SAME object
+    // (the glass pane in front of the second light), but almost never all lanes of a wave at once, so a
+    // wave-uniform early out does not fire. Here the wave remembers, per light, the object that blocked
+    // everything for most lanes (learnt in the ordinary loop, LEARN) and tests that object first. A
+    // (lane, sample) ray it does not block is evaluated at once (T * brdf * light / 4, the radiance it carries
+    // if it arrives) and put on a list in LDS; whenever the list holds 64 rays the wave tests them against the
+    // whole scene, one ray per lane, and adds what arrives to the pixel sums `acc` (pixel slot `pix`).
+    // Occlusion is an OR over objects, so every ray gets the decision direct_light gives it; only the order of
+    // the f32 additions into the pixel sum differs. Returns the part that is not deferred.
+    uint32_t pending = 0;  // wave-uniform
+    __device__ __forceinline__ void process_pairs(NeeShare *sh, float *acc, uint32_t first, uint32_t count) {
+        const unsigned long long act = __ballot(true);
+        const uint32_t n_act = (uint32_t)__popcll(act);
+        uint32_t d0 = 0, d1 = 0;
+        wave_lds_sync();
+        for (uint32_t i = rank_in(act); i < count; i += n_act) {
+            const float *pr = sh->pair + first + i;
+            F3 px = F3{pr[0], pr[kPairCap], pr[2 * kPairCap]};
+            F3 pl[1] = {F3{pr[3 * kPairCap], pr[4 * kPairCap], pr[5 * kPairCap]}};
+            float pt[1] = {pr[6 * kPairCap]};
+            bool po[1];
+            occluded_multi<Tbl, 1, false>(tbl, P, px, 1e-4f, pl, pt, po, d0, d1);
+            if (!po[0]) {
+                float *a = acc + __float_as_uint(pr[10 * kPairCap]) * 3u;
+                __hip_atomic_fetch_add(a + 0, pr[7 * kPairCap], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(a + 1, pr[8 * kPairCap], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(a + 2, pr[9 * kPairCap], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        wave_lds_sync();
+    }
+    // after the trace loop, all lanes of the wave: the rays still on the list
+    __device__ __forceinline__ void flush_pairs(NeeShare *sh, float *acc) {
+        wave_lds_sync();
+        uint32_t n = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (n) process_pairs(sh, acc, 0u, n);
+    }
+    __device__ __forceinline__ F3 direct_light_shared(bool nee, F3 x, const ShadeK &sk, Rng &rng, F3 T, uint32_t pix,
+                                                      NeeShare *sh, float *acc) {
+        static_assert(!COUNT && !BVH, "the counting and LBVH kernels use direct_light");
+        F3 total = F3{0.0f, 0.0f, 0.0f};
+        const uint32_t n_nee = (uint32_t)__popcll(__ballot(nee));
+        if (n_nee == 0u) return total;
+        uint32_t dummy0 = 0, dummy1 = 0;
+#ifdef PT_NEE_DIAG
+        const bool diag_lane = rank_in(__ballot(true)) == 0u;
+#define NEE_DIAG(k, v) if (diag_lane && li < 3u) atomicAdd(&diag[k], (unsigned long long)(v))
+#else
+#define NEE_DIAG(k, v)
+#endif
+        for (uint32_t li = 0; li < P.n_light; ++li) {
+            uint32_t o = P.light_off + li * LIGHT_F4;
+            float4 l0 = tbl.ld(o), l1 = tbl.ld(o + 1), l2 = tbl.ld(o + 2), l3 = tbl.ld(o + 3), l4 = tbl.ld(o + 4);
+            NEE_DIAG(li * 4u, 1);
+            F3 l[4];
+            float id2[4], tmax[4];
+            if (nee) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    float e1 = rng.gen() - 0.5f;
+                    float e2 = rng.gen() - 0.5f;
+                    F3 lp = f3(l0) + f3(l1) * e1 + f3(l2) * e2;
+                    F3 lvec = lp - x;
+                    float dist2 = dot(lvec, lvec);
+                    float inv = rsq(dist2);
+                    l[s] = lvec * inv;
+                    id2[s] = inv * inv;
+                    tmax[s] = (dist2 * inv) * 0.99949987493746f;  // |lvec| sqrt(0.999)
+                }
+            }
+            uint32_t h = kNoHint;
+            if (li < kHintLights)
+                h = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->hint[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            bool full = true;
+            if (h != kNoHint) {
+                uint32_t surv = 0;  // bit s: sample s is lit from the front and not blocked by the remembered object
+                if (nee) {
+                    bool hit[4];
+                    object_shadow<Tbl, 4>(tbl, P, h, x, 1e-4f, l, tmax, hit);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)  // a sample that faces away contributes nothing (:50,:55)
+                        if (!hit[s] & (dot(sk.n, l[s]) > 0.0f) & (-dot(l[s], f3(l4)) > 0.0f)) surv |= 1u << s;
+                }
+                const unsigned long long b0 = __ballot((surv & 1u) != 0u), b1 = __ballot((surv & 2u) != 0u),
+                                         b2 = __ballot((surv & 4u) != 0u), b3 = __ballot((surv & 8u) != 0u);
+                const uint32_t n0 = (uint32_t)__popcll(b0), n1 = n0 + (uint32_t)__popcll(b1), n2 = n1 + (uint32_t)__popcll(b2),
+                               n = n2 + (uint32_t)__popcll(b3);
+                if (n <= kPairBatch) {
+                    full = false;
+                    if (n == 0u) NEE_DIAG(li * 4u + 1u, 1);
+                    if (n != 0u) {
+                        NEE_DIAG(li * 4u + 2u, 1);
+                        NEE_DIAG(li * 4u + 3u, n);
+                        const unsigned long long bs[4] = {b0, b1, b2, b3};
+                        const uint32_t base[4] = {0u, n0, n1, n2};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            if (surv & (1u << s)) {
+                                bool lit;
+                                F3 c = T * nee_eval(sk, l[s], id2[s], f3(l4), l0.w, f3(l3), lit) * 0.25f;  // :82
+                                float *pr = sh->pair + pending + base[s] + rank_in(bs[s]);
+                                pr[0] = x.x, pr[kPairCap] = x.y, pr[2 * kPairCap] = x.z;
+                                pr[3 * kPairCap] = l[s].x, pr[4 * kPairCap] = l[s].y, pr[5 * kPairCap] = l[s].z;
+                                pr[6 * kPairCap] = tmax[s];
+                                pr[7 * kPairCap] = c.x, pr[8 * kPairCap] = c.y, pr[9 * kPairCap] = c.z;
+                                pr[10 * kPairCap] = __uint_as_float(pix);
+                            }
+                        pending += n;
+                        if (pending >= kPairBatch) {
+                            pending -= kPairBatch;
+                            process_pairs(sh, acc, pending, kPairBatch);
+                        }
+                        __hip_atomic_store(&sh->pending, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                } else {  // the remembered object no longer blocks most of the wave's samples
+                    NEE_DIAG(12u + li, 1);
+                    __hip_atomic_store(&sh->hint[li], kNoHint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            if (full && nee) {
+                bool occ[4];
+                uint32_t dom, dom_lanes;
+                occluded_multi<Tbl, 4, false, true>(tbl, P, x, 1e-4f, l, tmax, occ, dummy0, dummy1, true, &dom, &dom_lanes);
+                // worth remembering if the lanes it leaves over fit a batch: at most 4 rays each
+                if (li < kHintLights && dom_lanes != 0u && (n_nee - dom_lanes) * 4u <= 56u)
+                    __hip_atomic_store(&sh->hint[li], dom, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                F3 contrib = F3{0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (!occ[s]) {
+                        bool lit;
+                        contrib = contrib + nee_eval(sk, l[s], id2[s], f3(l4), l0.w, f3(l3), lit);
+                    }
+                }
+                total = madd(total, contrib, 0.25f);  // :82
+            }
         }
         return total;
     }

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void wf_extend(Params P, const float4 *__restr
                 uint32_t px = pix % P.width, py = pix / P.width;
                 rng.seed(seed_mixed, mix32(pix + seed_mixed), next);
                 float jx = rng.gen(), jy = rng.gen(), ds = rng.gen(), dt = rng.gen();
-                camera_ray(P, px, py, jx, jy, ds, dt, ro, rd);
+                camera_ray(tbl, P, px, py, jx, jy, ds, dt, ro, rd);
                 depth = 0;
                 media = -1;
                 alive = true;

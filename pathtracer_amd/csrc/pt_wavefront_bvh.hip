@@ -39,12 +39,12 @@ constexpr uint32_t kFetchChunk = 256;          // rays a wave reserves with one 
 constexpr uint32_t kFetchMin = WFB_FETCH_MIN;  // idle lanes that trigger a refill
 
 // renderer.rs:170-178: the pixel's next camera path
-__device__ __forceinline__ void new_camera_path(const Params &P, uint32_t seed_mixed, uint32_t pix, uint32_t &next, Rng &rng,
+__device__ __forceinline__ void new_camera_path(const TblGlobal &tbl, const Params &P, uint32_t seed_mixed, uint32_t pix, uint32_t &next, Rng &rng,
                                                 F3 &ro, F3 &rd, F3 &T, uint32_t &depth, int &media) {
     uint32_t px = pix % P.width, py = pix / P.width;
     rng.seed(seed_mixed, mix32(pix + seed_mixed), next);
     float jx = rng.gen(), jy = rng.gen(), ds = rng.gen(), dt = rng.gen();
-    camera_ray(P, px, py, jx, jy, ds, dt, ro, rd);
+    camera_ray(tbl, P, px, py, jx, jy, ds, dt, ro, rd);
     T = F3{1, 1, 1};
     depth = 0;
     media = -1;
@@ -67,15 +67,16 @@ __device__ __forceinline__ void push_ray(const WfQueue &Q, uint32_t pos, uint32_
 }  // namespace
 
 // Every pixel starts with the camera path of its first sample; entries of the ray queue are always live rays.
-__global__ __launch_bounds__(256) void wfb_init(Params P, WfQueue Q, uint32_t n) {
+__global__ __launch_bounds__(256) void wfb_init(Params P, const float4 *__restrict__ blob, WfQueue Q, uint32_t n) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
+    TblGlobal tbl{blob};
     const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
     uint32_t next = P.sample_begin, depth;
     int media;
     Rng rng{0u, 1u};
     F3 ro, rd, T;
-    new_camera_path(P, seed_mixed, i, next, rng, ro, rd, T, depth, media);
+    new_camera_path(tbl, P, seed_mixed, i, next, rng, ro, rd, T, depth, media);
     push_ray(Q, i, i, depth, media, next, F3{0, 0, 0}, ro, rd, T, rng);
     if (i == 0) *Q.count = n;
 }
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restr
             }
             if (!to_shade) {
                 if (!alive && next < s_end) {  // the pixel's next sample takes the finished path's place
-                    new_camera_path(P, seed_mixed, pix, next, rng, ro, rd, T, depth, media);
+                    new_camera_path(tbl, P, seed_mixed, pix, next, rng, ro, rd, T, depth, media);
                     alive = true;
                 }
                 to_next = alive;
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
             ++depth;
             if (depth >= P.max_depth) alive = false;
             if (!alive && next < s_end) {
-                new_camera_path(P, seed_mixed, pix, next, rng, ro, rd, T, depth, media);
+                new_camera_path(tbl, P, seed_mixed, pix, next, rng, ro, rd, T, depth, media);
                 alive = true;
             }
             to_next = alive;
@@ -590,7 +591,7 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
     hipError_t e;
     if ((e = hipMemsetAsync(counters, 0, 4096, st)) != hipSuccess) return e;
     if (P.sample_count == 0) return hipSuccess;
-    hipLaunchKernelGGL(wfb_init, dim3(blocks_all), dim3(256), 0, st, P, Q[0], n);
+    hipLaunchKernelGGL(wfb_init, dim3(blocks_all), dim3(256), 0, st, P, blob, Q[0], n);
     const uint32_t max_iter = P.sample_count * P.max_depth + 1;
     uint32_t it = 0;
     int cur = 0;

@@ -88,7 +88,11 @@ def test_sample_slices_change_only_the_summation_order():
         b, cb = hip_renderer.render_accum(s, seed=4, counters=True, flags=_abi.FLAG_NO_SLICES)
         assert ca == cb
         assert np.allclose(a, b, rtol=3e-6, atol=1e-6)
-        assert np.array_equal(a, hip_renderer.render_accum(s, seed=4))
+        # the plain kernel (no counters) defers part of the shadow rays and adds what they carry to the pixel
+        # sums separately (Tracer::direct_light_shared): same rays, same decisions, another order of additions
+        c = hip_renderer.render_accum(s, seed=4)
+        _compare(a, c, spp)  # two instantiations, contracted/scheduled independently by hipcc
+        assert np.array_equal(c, hip_renderer.render_accum(s, seed=4))
 
 
 def test_sample_ranges_add_up():
