@@ -23,10 +23,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU (packed f32)
-# HBM bytes of one megakernel launch at 1920x1080 from the PMC passes in profiles/r01_megakernel_v6_traffic_pmc.txt
-# (FETCH_SIZE 2035.6 KB, doubled per the gfx950 correction, + WRITE_SIZE 203798 KB; the launch writes 8 sample
-# slices of partial sums, 24.9 MB each, whatever the sample count; pt_add_partials then reads them once). Counters cannot be read inside this process.
-MEGAKERNEL_1080P_TRAFFIC_BYTES = int((2 * 2035.6 + 203798.0) * 1024)
+# HBM bytes of one megakernel launch at 1920x1080 x 1024 spp from the PMC passes in profiles/r01_megakernel_v7_traffic_pmc.txt
+# (FETCH_SIZE 20936 KB, doubled per the gfx950 correction, + WRITE_SIZE 1.629e8 KB). The image itself is 8 sample
+# slices of partial sums, 24.9 MB each (199 MB; pt_add_partials then reads them once); the rest, 167 GB, is
+# write-through of register spills: the kernel holds 11 dwords per lane in scratch across the lights loop of every
+# trip ("spills"). Counters cannot be read inside this process.
+MEGAKERNEL_1080P_TRAFFIC_BYTES = int((2 * 20936.4 + 1.62898e8) * 1024)
 
 
 def cpu_baseline(threads):
@@ -162,12 +164,13 @@ def main():
             "flop_per_path": round(fl / cn["paths"], 1),
             "roofline": {"bound": "valu_fp32", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
-                         "traffic": MEGAKERNEL_1080P_TRAFFIC_BYTES if (W, H, args.flags, args.config) == (1920, 1080, 0, "c2") and not args.scene else None,
+                         "traffic": MEGAKERNEL_1080P_TRAFFIC_BYTES if (W, H, args.spp, args.flags, args.config) == (1920, 1080, 1024, 0, "c2") and not args.scene else None,
                          "kernel_ms": round(k_ms, 3), "launches_per_step": launches // args.steps,
                          "note": "algorithmic FLOPs (SURVEY §8d event costs x device event counters of this step) / "
                                  "mean trace-kernel duration from HIP events on the launch stream; the path is "
                                  "VALU-bound (no MFMA); traffic = HBM bytes per launch from the committed PMC passes "
-                                 "(profiles/r01_megakernel_v6_traffic_pmc.txt), ~103 B per pixel per launch"},
+                                 "(profiles/r01_megakernel_v7_traffic_pmc.txt): 0.2 GB of image partial sums, the rest scratch "
+                                 "write-through of 11 spilled dwords per lane and trip (0.49 TB/s, 6 % of HBM peak)"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))

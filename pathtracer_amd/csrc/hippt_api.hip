@@ -47,8 +47,9 @@ namespace {
 // Paths per launch: bounds one launch to a fraction of a second so that long
 // renders stay observable (analogue of the 600 M budget, gpu_renderer.rs:94).
 constexpr uint64_t kPathsPerLaunch = 4ull << 30;
-// LDS budget for the staged tables (default dynamic LDS limit per block).
-constexpr size_t kMaxLdsBlob = 60 * 1024;
+// LDS budget for the staged tables: a block may use 64 KiB without opting in to more, and the megakernel
+// keeps 4 x WaveLds (pixel sums, pending shadow rays) of static LDS beside the tables.
+const size_t kMaxLdsBlob = 64 * 1024 - pt::megakernel_static_lds();
 // Sphere count from which hippt_set_scene builds the LBVH (brute force wins below).
 constexpr uint32_t kBvhMinSpheres = 64;
 

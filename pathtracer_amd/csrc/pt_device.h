@@ -46,7 +46,8 @@ __device__ __forceinline__ F3 operator-(F3 a, F3 b) { return F3{a.x - b.x, a.y -
 __device__ __forceinline__ F3 operator*(F3 a, F3 b) { return F3{a.x * b.x, a.y * b.y, a.z * b.z}; }
 __device__ __forceinline__ F3 operator*(F3 a, float s) { return F3{a.x * s, a.y * s, a.z * s}; }
 __device__ __forceinline__ F3 operator-(F3 a) { return F3{-a.x, -a.y, -a.z}; }
-__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// the contraction is spelt out, so that every inlined copy of a test rounds the same way
+__device__ __forceinline__ float dot(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 __device__ __forceinline__ F3 cross(F3 a, F3 b) {
     return F3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
@@ -311,6 +312,7 @@ __device__ __forceinline__ float sub_unfused(float a, float b) {
 template <int NS>
 __device__ __forceinline__ void sphere_shadow_row(float4 c, F3 x, float eps, const F3 (&l)[NS], const float (&q)[NS],
                                                   bool (&hit)[NS]) {
+#pragma clang fp contract(off)  // explicit fmaf only: the copies of this test (NS = 1, NS = 4, object_shadow) must agree bit for bit
     F3 X = x - f3(c);
     float C0 = fmaf(X.z, X.z, fmaf(X.y, X.y, fmaf(X.x, X.x, -c.w)));  // X.X - r^2
 #pragma unroll
@@ -326,6 +328,7 @@ __device__ __forceinline__ void sphere_shadow_row(float4 c, F3 x, float eps, con
 template <int NS>
 __device__ __forceinline__ void plane_shadow_row(float4 q0, float4 q1, float4 q2, F3 x, float eps, const F3 (&l)[NS],
                                                  const float (&q)[NS], bool (&hit)[NS]) {
+#pragma clang fp contract(off)
     F3 n = F3{q0.w, q1.x, q1.y}, u = F3{q1.z, q1.w, q2.x}, v = F3{q2.y, q2.z, q2.w};
     F3 Xp = x - f3(q0);
     float Dn = -dot(Xp, n), Du = dot(Xp, u), Dv = dot(Xp, v);

@@ -44,6 +44,8 @@ hipError_t launch_unit_glass(uint32_t n, const float *rd, const float *nrm, cons
                              float *out, hipStream_t st);
 hipError_t launch_unit_hg(uint32_t n, const float *rd, const float *g, const float *u_hg, const float *u_phi,
                           float *out4, hipStream_t st);
+// static LDS per block of the megakernels (4 x WaveLds)
+size_t megakernel_static_lds();
 hipError_t launch_unit_camera(const Params &P, const float4 *blob, uint32_t n, const uint32_t *xy, const float *u4, float *out_ro,
                               float *out_rd, hipStream_t st);
 hipError_t launch_unit_tonemap(uint32_t n3, const float *rgb, uint8_t *out, hipStream_t st);

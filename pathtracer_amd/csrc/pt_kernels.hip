@@ -569,6 +569,7 @@ hipError_t launch_unit_hg(uint32_t n, const float *rd, const float *g, const flo
     hipLaunchKernelGGL(pt_unit_hg, dim3(grid_for(n)), dim3(256), 0, st, n, rd, g, u_hg, u_phi, out4);
     return hipGetLastError();
 }
+size_t megakernel_static_lds() { return 4 * sizeof(WaveLds); }
 hipError_t launch_unit_camera(const Params &P, const float4 *blob, uint32_t n, const uint32_t *xy, const float *u4, float *out_ro,
                               float *out_rd, hipStream_t st) {
     hipLaunchKernelGGL(pt_unit_camera, dim3(grid_for(n)), dim3(256), 0, st, P, blob, n, xy, u4, out_ro, out_rd);

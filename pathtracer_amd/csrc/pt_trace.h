@@ -8,6 +8,9 @@
 namespace pt {
 
 // Per-wave LDS of Tracer::direct_light_shared.
+#ifndef PT_HINT_SLACK
+#define PT_HINT_SLACK 128u
+#endif
 constexpr uint32_t kHintLights = 8;  // lights that keep a remembered occluder
 constexpr uint32_t kNoHint = 0xffffffffu;
 constexpr uint32_t kPairCap = 128;   // pending shadow rays: < 64 left over + at most 64 new ones per light
@@ -15,7 +18,7 @@ constexpr uint32_t kPairBatch = 64;
 constexpr uint32_t kPairWords = 11;  // x, l, tmax, the radiance the ray carries if it arrives, pixel slot
 struct NeeShare {
     uint32_t hint[kHintLights];  // per light: the object that last blocked all 4 samples of most lanes
-    uint32_t pending;            // rays in the list (copy of Tracer::pending for the lanes that leave the loop last)
+    uint32_t pending;            // rays in the list
     float pair[kPairWords * kPairCap];  // word-major list of shadow rays not yet tested against the whole scene
 };
 
@@ -139,7 +142,6 @@ struct Tracer {
     // whole scene, one ray per lane, and adds what arrives to the pixel sums `acc` (pixel slot `pix`).
     // Occlusion is an OR over objects, so every ray gets the decision direct_light gives it; only the order of
     // the f32 additions into the pixel sum differs. Returns the part that is not deferred.
-    uint32_t pending = 0;  // wave-uniform
     __device__ __forceinline__ void process_pairs(NeeShare *sh, float *acc, uint32_t first, uint32_t count) {
         const unsigned long long act = __ballot(true);
         const uint32_t n_act = (uint32_t)__popcll(act);
@@ -173,6 +175,8 @@ struct Tracer {
         F3 total = F3{0.0f, 0.0f, 0.0f};
         const uint32_t n_nee = (uint32_t)__popcll(__ballot(nee));
         if (n_nee == 0u) return total;
+        // not kept in a register across trips: a lane whose pool item lies outside the image skips the trip
+        uint32_t pending = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         uint32_t dummy0 = 0, dummy1 = 0;
 #ifdef PT_NEE_DIAG
         const bool diag_lane = rank_in(__ballot(true)) == 0u;
@@ -204,8 +208,10 @@ struct Tracer {
             if (li < kHintLights)
                 h = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->hint[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             bool full = true;
+            uint32_t surv = 0;  // bit s: evaluate sample s (hinted: lit from the front and not blocked by the remembered object)
+            uint32_t hinted_n = 0, base[4];
+            unsigned long long bs[4];
             if (h != kNoHint) {
-                uint32_t surv = 0;  // bit s: sample s is lit from the front and not blocked by the remembered object
                 if (nee) {
                     bool hit[4];
                     object_shadow<Tbl, 4>(tbl, P, h, x, 1e-4f, l, tmax, hit);
@@ -219,34 +225,18 @@ struct Tracer {
                                n = n2 + (uint32_t)__popcll(b3);
                 if (n <= kPairBatch) {
                     full = false;
+                    hinted_n = n;
+                    base[0] = pending, base[1] = pending + n0, base[2] = pending + n1, base[3] = pending + n2;
+                    bs[0] = b0, bs[1] = b1, bs[2] = b2, bs[3] = b3;
                     if (n == 0u) NEE_DIAG(li * 4u + 1u, 1);
                     if (n != 0u) {
                         NEE_DIAG(li * 4u + 2u, 1);
                         NEE_DIAG(li * 4u + 3u, n);
-                        const unsigned long long bs[4] = {b0, b1, b2, b3};
-                        const uint32_t base[4] = {0u, n0, n1, n2};
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            if (surv & (1u << s)) {
-                                bool lit;
-                                F3 c = T * nee_eval(sk, l[s], id2[s], f3(l4), l0.w, f3(l3), lit) * 0.25f;  // :82
-                                float *pr = sh->pair + pending + base[s] + rank_in(bs[s]);
-                                pr[0] = x.x, pr[kPairCap] = x.y, pr[2 * kPairCap] = x.z;
-                                pr[3 * kPairCap] = l[s].x, pr[4 * kPairCap] = l[s].y, pr[5 * kPairCap] = l[s].z;
-                                pr[6 * kPairCap] = tmax[s];
-                                pr[7 * kPairCap] = c.x, pr[8 * kPairCap] = c.y, pr[9 * kPairCap] = c.z;
-                                pr[10 * kPairCap] = __uint_as_float(pix);
-                            }
-                        pending += n;
-                        if (pending >= kPairBatch) {
-                            pending -= kPairBatch;
-                            process_pairs(sh, acc, pending, kPairBatch);
-                        }
-                        __hip_atomic_store(&sh->pending, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 } else {  // the remembered object no longer blocks most of the wave's samples
                     NEE_DIAG(12u + li, 1);
                     __hip_atomic_store(&sh->hint[li], kNoHint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    surv = 0;
                 }
             }
             if (full && nee) {
@@ -254,17 +244,43 @@ struct Tracer {
                 uint32_t dom, dom_lanes;
                 occluded_multi<Tbl, 4, false, true>(tbl, P, x, 1e-4f, l, tmax, occ, dummy0, dummy1, true, &dom, &dom_lanes);
                 // worth remembering if the lanes it leaves over fit a batch: at most 4 rays each
-                if (li < kHintLights && dom_lanes != 0u && (n_nee - dom_lanes) * 4u <= 56u)
+                if (li < kHintLights && dom_lanes != 0u && (n_nee - dom_lanes) * 4u <= PT_HINT_SLACK)
                     __hip_atomic_store(&sh->hint[li], dom, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (!occ[s]) surv |= 1u << s;
+            }
+            // ONE evaluation site for both cases (two inlined copies could be contracted differently, and a
+            // roughness-0.01 highlight amplifies a last-bit difference 1e4 times): surv = samples to evaluate
+            if (surv != 0u) {
                 F3 contrib = F3{0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    if (!occ[s]) {
+                    if (surv & (1u << s)) {
                         bool lit;
-                        contrib = contrib + nee_eval(sk, l[s], id2[s], f3(l4), l0.w, f3(l3), lit);
+                        F3 c = nee_eval(sk, l[s], id2[s], f3(l4), l0.w, f3(l3), lit);
+                        if (full) {
+                            contrib = contrib + c;
+                        } else {
+                            c = T * c * 0.25f;  // :82, and the path throughput (:285 / :325)
+                            float *pr = sh->pair + base[s] + rank_in(bs[s]);
+                            pr[0] = x.x, pr[kPairCap] = x.y, pr[2 * kPairCap] = x.z;
+                            pr[3 * kPairCap] = l[s].x, pr[4 * kPairCap] = l[s].y, pr[5 * kPairCap] = l[s].z;
+                            pr[6 * kPairCap] = tmax[s];
+                            pr[7 * kPairCap] = c.x, pr[8 * kPairCap] = c.y, pr[9 * kPairCap] = c.z;
+                            pr[10 * kPairCap] = __uint_as_float(pix);
+                        }
                     }
                 }
                 total = madd(total, contrib, 0.25f);  // :82
+            }
+            if (hinted_n != 0u) {
+                pending += hinted_n;
+                if (pending >= kPairBatch) {
+                    pending -= kPairBatch;
+                    process_pairs(sh, acc, pending, kPairBatch);
+                }
+                __hip_atomic_store(&sh->pending, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         return total;

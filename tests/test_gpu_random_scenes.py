@@ -104,3 +104,20 @@ def test_random_scene_render_and_hits(oracle, hip, seed, n_sph, n_pl, n_light):
         acc_w = hip_renderer.render_accum(s, seed=seed, flags=_abi.FLAG_WAVEFRONT)
         rw = np.abs(acc_w.astype(np.float64) - acc_h).max(axis=2) / np.maximum(np.abs(acc_h).max(axis=2), 1e-3 * s.samples)
         assert np.quantile(rw, 0.9) < 1e-4, np.quantile(rw, [0.5, 0.9, 0.99])
+
+
+def test_tables_near_the_lds_budget(oracle):
+    """700 rectangles: the tables (45 KB) no longer fit beside the megakernel's own LDS, so the launch must pick
+    the global-memory tables by itself, and 400 rectangles (26 KB) still render from LDS; both match the oracle."""
+    from pathtracer_amd import hip_renderer, _abi
+    for n_pl in (400, 700):
+        s = random_scene(77, 3, n_pl, 2, w=32, h=24, spp=4)
+        a = hip_renderer.render_accum(s, seed=1)
+        b = hip_renderer.render_accum(s, seed=1, flags=_abi.FLAG_TABLES_GLOBAL)
+        xs, ys = np.meshgrid(np.arange(0, 32, 3), np.arange(0, 24, 3))
+        xys = np.stack([np.repeat(xs.ravel(), 4), np.repeat(ys.ravel(), 4), np.tile(np.arange(4), xs.size)], 1)
+        ref = oracle.paths(s, xys, seed=1, iterative=True).astype(np.float64).reshape(xs.size, 4, 3).sum(axis=1)
+        for got in (a, b):
+            g = got[ys.ravel(), xs.ravel()].astype(np.float64)
+            r = np.abs(g - ref).max(axis=1) / np.maximum(np.abs(ref).max(axis=1), 4e-3)
+            assert np.quantile(r, 0.5) < 2e-6 and np.quantile(r, 0.9) < 1e-3, (n_pl, np.quantile(r, [0.5, 0.9, 0.99]))
