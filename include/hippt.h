@@ -138,7 +138,7 @@ enum {
     HIPPT_C_EXTEND_RAYS = 1,
     HIPPT_C_EXTEND_HITS = 2,
     HIPPT_C_SHADOW_RAYS = 3,
-    HIPPT_C_SHADOW_SPHERE_TESTS = 4, /* as executed (per-lane early out) */
+    HIPPT_C_SHADOW_SPHERE_TESTS = 4, /* as the reference executes them: scene order, up to a ray's first occluder (renderer.rs:46) */
     HIPPT_C_SHADOW_PLANE_TESTS = 5,
     HIPPT_C_NEE_VERTICES = 6,        /* opaque + scatter vertices */
     HIPPT_C_LIT_EVALS = 7,           /* unoccluded, front-facing shadow samples */

@@ -380,12 +380,21 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
     float q[NS];
     shadow_mid<NS>(eps, tmax, q);
     uint32_t best = 0xffffffffu, best_lanes = 0;
+    uint32_t first[NS];  // COUNT: scene order of the ray's first occluder
+#pragma unroll
+    for (int s = 0; s < NS; ++s) first[s] = 0xffffffffu;
     auto fold = [&](const bool (&hit)[NS], uint32_t obj) {
         bool all = true;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             occ[s] = occ[s] | hit[s];
             all = all & hit[s];
+        }
+        if (COUNT && spheres) {
+            const uint32_t ord = __float_as_uint(tbl.ld(P.aux_off + obj).z);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if (hit[s]) first[s] = min(first[s], ord);
         }
         if (LEARN) {
             uint32_t c = (uint32_t)__popcll(__ballot(all));
@@ -401,7 +410,6 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
         sphere_shadow_row<NS>(tbl.ld(P.sph_off + i), x, eps, l, q, hit);
         fold(hit, i);
     }
-    if (COUNT) n_sph_tests += NS * n_sph;
 #pragma unroll 1
     for (uint32_t j = 0; j < P.n_pl; ++j) {
         uint32_t o = P.pl_off + j * 3u;
@@ -409,7 +417,21 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
         plane_shadow_row<NS>(tbl.ld(o), tbl.ld(o + 1), tbl.ld(o + 2), x, eps, l, q, hit);
         fold(hit, P.n_sph + j);
     }
-    if (COUNT) n_pl_tests += NS * P.n_pl;
+    if (COUNT) {
+        // The counters report the tests the REFERENCE executes (renderer.rs:46 walks the objects in scene order and
+        // leaves at the first occluder), not the ones this loop runs: they feed the algorithmic FLOP count
+        // (SURVEY §8d), which must not depend on how the kernel orders or skips its work.
+        if (spheres) {
+            for (uint32_t i = 0; i < P.n_sph + P.n_pl; ++i) {
+                const uint32_t ord = __float_as_uint(tbl.ld(P.aux_off + i).z);
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    if (ord <= first[s]) (i < P.n_sph ? n_sph_tests : n_pl_tests) += 1u;
+            }
+        } else {  // LBVH kernels: sphere tests are counted by the traversal, plane tests as run
+            n_pl_tests += NS * P.n_pl;
+        }
+    }
     if (LEARN) {
         *dominant = best;
         *dominant_lanes = best_lanes;

@@ -52,10 +52,10 @@ def test_example_scene_sample_exact(oracle):
               "spec_lobes", "glass_vertices", "extend_sphere_tests", "extend_plane_tests"):
         assert abs(cn_h[k] - cn_o[k]) <= 2e-3 * cn_o[k] + 8, (k, cn_h[k], cn_o[k])
     assert cn_h["medium_vertices"] == 0 and cn_h["scatter_events"] == 0
-    # shadow tests are counted as executed: the oracle leaves at a ray's first occluder, the kernel
-    # only when its whole wave is occluded
-    assert cn_o["shadow_sphere_tests"] <= cn_h["shadow_sphere_tests"] <= 3 * cn_h["shadow_rays"]
-    assert cn_o["shadow_plane_tests"] <= cn_h["shadow_plane_tests"] <= 4 * cn_h["shadow_rays"]
+    # shadow tests are counted as the reference executes them (scene order, up to the first occluder), whatever
+    # the kernel itself runs: the algorithmic FLOP count must not depend on the kernel's shortcuts
+    for k in ("shadow_sphere_tests", "shadow_plane_tests"):
+        assert abs(cn_h[k] - cn_o[k]) <= 2e-3 * cn_o[k] + 8, (k, cn_h[k], cn_o[k])
 
 
 def test_matte_scene_tight(oracle):

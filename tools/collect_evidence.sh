@@ -1,3 +1,5 @@
+# Round evidence for the megakernel on the GPU box (from the repo root): GPU tests, bench lines, rocprofv3 kernel stats,
+# PMC and HBM-traffic passes, all under gpurun_out/v7/; copy what is to be kept into profiles/.
 set -u
 timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/t.log 2>&1 || { tail -30 gpurun_out/t.log; exit 1; }
 tail -2 gpurun_out/t.log
