@@ -56,6 +56,9 @@ __device__ __forceinline__ F3 madd(F3 a, F3 b, float s) {
     return F3{fmaf(b.x, s, a.x), fmaf(b.y, s, a.y), fmaf(b.z, s, a.z)};
 }
 
+// lanes of the wave (among the active ones) for which p holds; unlike __ballot(), which goes through a 0/1
+// VGPR (v_cndmask + v_cmp), this is the compare mask itself
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -397,7 +400,7 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
                 if (hit[s]) first[s] = min(first[s], ord);
         }
         if (LEARN) {
-            uint32_t c = (uint32_t)__popcll(__ballot(all));
+            uint32_t c = (uint32_t)__popcll(ballot64(all));
             if (c > best_lanes) {
                 best_lanes = c;
                 best = obj;

@@ -68,7 +68,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
 
     if (__any(in_image))
     for (;;) {
-        const unsigned long long need = __ballot(!alive);
+        const unsigned long long need = ballot64(!alive);
         if (need != 0ull) {
             uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
             uint32_t pos = cur_lane + rank;

@@ -143,7 +143,7 @@ struct Tracer {
     // Occlusion is an OR over objects, so every ray gets the decision direct_light gives it; only the order of
     // the f32 additions into the pixel sum differs. Returns the part that is not deferred.
     __device__ __forceinline__ void process_pairs(NeeShare *sh, float *acc, uint32_t first, uint32_t count) {
-        const unsigned long long act = __ballot(true);
+        const unsigned long long act = ballot64(true);
         const uint32_t n_act = (uint32_t)__popcll(act);
         uint32_t d0 = 0, d1 = 0;
         wave_lds_sync();
@@ -173,13 +173,13 @@ struct Tracer {
                                                       NeeShare *sh, float *acc) {
         static_assert(!COUNT && !BVH, "the counting and LBVH kernels use direct_light");
         F3 total = F3{0.0f, 0.0f, 0.0f};
-        const uint32_t n_nee = (uint32_t)__popcll(__ballot(nee));
+        const uint32_t n_nee = (uint32_t)__popcll(ballot64(nee));
         if (n_nee == 0u) return total;
         // not kept in a register across trips: a lane whose pool item lies outside the image skips the trip
         uint32_t pending = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         uint32_t dummy0 = 0, dummy1 = 0;
 #ifdef PT_NEE_DIAG
-        const bool diag_lane = rank_in(__ballot(true)) == 0u;
+        const bool diag_lane = rank_in(ballot64(true)) == 0u;
 #define NEE_DIAG(k, v) if (diag_lane && li < 3u) atomicAdd(&diag[k], (unsigned long long)(v))
 #else
 #define NEE_DIAG(k, v)
@@ -219,8 +219,8 @@ struct Tracer {
                     for (int s = 0; s < 4; ++s)  // a sample that faces away contributes nothing (:50,:55)
                         if (!hit[s] & (dot(sk.n, l[s]) > 0.0f) & (-dot(l[s], f3(l4)) > 0.0f)) surv |= 1u << s;
                 }
-                const unsigned long long b0 = __ballot((surv & 1u) != 0u), b1 = __ballot((surv & 2u) != 0u),
-                                         b2 = __ballot((surv & 4u) != 0u), b3 = __ballot((surv & 8u) != 0u);
+                const unsigned long long b0 = ballot64((surv & 1u) != 0u), b1 = ballot64((surv & 2u) != 0u),
+                                         b2 = ballot64((surv & 4u) != 0u), b3 = ballot64((surv & 8u) != 0u);
                 const uint32_t n0 = (uint32_t)__popcll(b0), n1 = n0 + (uint32_t)__popcll(b1), n2 = n1 + (uint32_t)__popcll(b2),
                                n = n2 + (uint32_t)__popcll(b3);
                 if (n <= kPairBatch) {
