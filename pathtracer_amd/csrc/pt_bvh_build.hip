@@ -65,9 +65,12 @@ __global__ void k_morton(const float4 *__restrict__ sph, uint32_t n, const uint3
     float4 s = sph[i];
     float c[3] = {s.x, s.y, s.z};
     uint32_t q[3];
+    // one cell size for the three axes (cubic Morton cells): with per-axis scaling a flat scene such as the C4 slab
+    // (80 x 12 x 80) is cut as often across its thin axis as along the others, which gives sliver boxes
+    float ext = 1e-30f;
+    for (int k = 0; k < 3; ++k) ext = fmaxf(ext, o2f(bounds[3 + k]) - o2f(bounds[k]));
     for (int k = 0; k < 3; ++k) {
-        float lo = o2f(bounds[k]), hi = o2f(bounds[3 + k]);
-        float ext = fmaxf(hi - lo, 1e-30f);
+        float lo = o2f(bounds[k]);
         float u = fminf(fmaxf((c[k] - lo) / ext * 1024.0f, 0.0f), 1023.0f);
         q[k] = (uint32_t)u;
     }
