@@ -172,6 +172,25 @@ int hippt_render_rgba8(const hippt_scene *scene, const hippt_options *opts,
 int hippt_render_accum_f32(const hippt_scene *scene, const hippt_options *opts,
                            float *out_accum, uint64_t *counters);
 
+/* ---- one process, several GPUs ---------------------------------------------
+ * The reference has one device and adds its dispatches up on the host
+ * (src/gpu_renderer.rs:94-102,175-179). Here the image's sample range is split
+ * over `devices` (hippt_sample_range), every device renders all pixels for its share of
+ * the global sample indices, and the f32 sums are added up on devices[0] with one
+ * RCCL reduce (librccl.so is opened at the first call; HIPPT_RCCL_LIB overrides the
+ * name) before the tonemap. The image does not depend on the number of devices
+ * beyond the order of the f32 additions. opts->device is ignored. */
+int hippt_render_rgba8_multi(const hippt_scene *scene, const hippt_options *opts,
+                             const int *devices, int n_devices, uint8_t *out_rgba);
+/* Radiance sums of opts' sample range (the whole image if its count is 0). */
+int hippt_render_accum_f32_multi(const hippt_scene *scene, const hippt_options *opts,
+                                 const int *devices, int n_devices, float *out_accum);
+/* Rank's share of `total` samples over `world` ranks: contiguous, counts differ by at
+ * most one (the reference over-renders an uneven last dispatch instead,
+ * gpu_renderer.rs:98-102). */
+void hippt_sample_range(uint32_t total, uint32_t rank, uint32_t world,
+                        uint32_t *begin, uint32_t *count);
+
 /* ---- resident-context entry points (bench, multi-GPU, repeated renders) -- */
 
 typedef struct hippt_context hippt_context;

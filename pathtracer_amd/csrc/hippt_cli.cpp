@@ -11,6 +11,8 @@
 //   --checkpoint PATH  after every chunk, save the accumulator + samples done to PATH
 //   --resume           start from PATH if it exists (same size and seed), render the remaining samples
 //   --preview          after every chunk, also write the image of the samples so far to the output path
+// Several GPUs in this process (sample-range split + one RCCL reduce, hippt_render_rgba8_multi):
+//   --devices 0,1,...  the HIP devices to use (not combined with --chunk / --checkpoint)
 #include <sys/stat.h>
 
 #include <chrono>
@@ -34,6 +36,7 @@ int main(int argc, char **argv) {
     bool have_spp = false, resume = false, preview = false;
     uint32_t chunk = 0;
     std::string ckpt_path;
+    std::vector<int> devices;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char * {
@@ -55,6 +58,17 @@ int main(int argc, char **argv) {
         else if (a == "--checkpoint") ckpt_path = next();
         else if (a == "--resume") resume = true;
         else if (a == "--preview") preview = true;
+        else if (a == "--devices") {
+            for (const char *p = next(); *p;) {
+                char *end = nullptr;
+                devices.push_back((int)std::strtol(p, &end, 10));
+                if (end == p) {
+                    std::fprintf(stderr, "--devices wants a comma-separated list of device numbers\n");
+                    return 2;
+                }
+                p = *end == ',' ? end + 1 : end;
+            }
+        }
     }
 
     hippt_scene_file *sf = nullptr;
@@ -117,7 +131,13 @@ int main(int argc, char **argv) {
     opt.device = device;
     auto t0 = std::chrono::steady_clock::now();
     uint32_t rendered = sc->samples;
-    if (chunk == 0 && ckpt_path.empty()) {
+    if (!devices.empty()) {
+        if (chunk != 0 || !ckpt_path.empty()) {
+            std::fprintf(stderr, "--devices is not combined with --chunk / --checkpoint\n");
+            return 2;
+        }
+        if (hippt_render_rgba8_multi(sc, &opt, devices.data(), (int)devices.size(), rgba.data())) die("render");
+    } else if (chunk == 0 && ckpt_path.empty()) {
         if (hippt_render_rgba8(sc, &opt, rgba.data())) die("render");
     } else {
         if (sc->samples == 0) {

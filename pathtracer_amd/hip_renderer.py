@@ -47,6 +47,36 @@ def render_accum(scene, sample_begin=0, sample_count=0, seed=0, device=0, max_de
     return out
 
 
+def render_multi(scene, devices, seed=0, max_depth=0, flags=0):
+    """gpu_renderer::render on several GPUs of this process: sample-range split, one RCCL reduce, tonemap on devices[0]."""
+    lib = _abi.load_library()
+    sc, _keep = scene.to_c()
+    out = np.empty((scene.height, scene.width, 4), np.uint8)
+    o = _opts(0, 0, max_depth, seed, flags, 0)
+    dv = (C.c_int * len(devices))(*devices)
+    _abi.check(lib.hippt_render_rgba8_multi(C.byref(sc), C.byref(o), dv, len(devices), out.ctypes.data_as(C.c_void_p)), lib)
+    return out
+
+
+def render_accum_multi(scene, devices, sample_begin=0, sample_count=0, seed=0, max_depth=0, flags=0):
+    """Radiance sums of a sample range rendered by several GPUs of this process and reduced with RCCL."""
+    lib = _abi.load_library()
+    sc, _keep = scene.to_c()
+    out = np.empty((scene.height, scene.width, 3), np.float32)
+    o = _opts(sample_begin, sample_count, max_depth, seed, flags, 0)
+    dv = (C.c_int * len(devices))(*devices)
+    _abi.check(lib.hippt_render_accum_f32_multi(C.byref(sc), C.byref(o), dv, len(devices), out.ctypes.data_as(C.c_void_p)), lib)
+    return out
+
+
+def sample_range(total, rank, world):
+    """hippt_sample_range: the C ABI's copy of pathtracer_amd.partition.sample_range."""
+    lib = _abi.load_library()
+    b, c = C.c_uint32(), C.c_uint32()
+    lib.hippt_sample_range(total, rank, world, C.byref(b), C.byref(c))
+    return b.value, c.value
+
+
 def unit_ops(device=0):
     """Unit-kernel exports (hippt_test_*) of the HIP library."""
     lib = _abi.load_library()

@@ -55,7 +55,14 @@ pub fn render(scene: &Scene) -> RgbaImage {
     };
     let opts = hippt_options { seed: rand::random(), ..Default::default() };
     let mut rgba = vec![0u8; (width * height * 4) as usize];
-    let rc = unsafe { hippt_render_rgba8(&c_scene, &opts, rgba.as_mut_ptr()) };
+    // HIPPT_DEVICES=0,1,...,7 renders on several GPUs of the node (sample-range split, RCCL reduce in the library)
+    let devices: Vec<i32> = std::env::var("HIPPT_DEVICES").ok()
+        .map(|s| s.split(',').filter_map(|d| d.trim().parse().ok()).collect()).unwrap_or_default();
+    let rc = if devices.is_empty() {
+        unsafe { hippt_render_rgba8(&c_scene, &opts, rgba.as_mut_ptr()) }
+    } else {
+        unsafe { hippt_render_rgba8_multi(&c_scene, &opts, devices.as_ptr(), devices.len() as i32, rgba.as_mut_ptr()) }
+    };
     if rc != 0 {
         let msg = unsafe { CStr::from_ptr(hippt_last_error()) }.to_string_lossy().into_owned();
         panic!("HIP renderer failed ({rc}): {msg}");       // same abort-with-message as gpu_renderer's `expect`s

@@ -15,7 +15,7 @@ fn main() {
     println!("cargo:rustc-link-search=native={}", lib.display());
     println!("cargo:rustc-link-lib=dylib=hippt");
     println!("cargo:rustc-link-arg=-Wl,-rpath,{}", lib.display());
-    for f in ["pt_kernels.hip", "pt_device.h", "hippt_api.hip", "host_scene.cpp"] {
+    for f in ["pt_kernels.hip", "pt_device.h", "pt_trace.h", "hippt_api.hip", "hippt_multi.hip", "host_scene.cpp"] {
         println!("cargo:rerun-if-changed={}", csrc.join(f).display());
     }
     println!("cargo:rerun-if-changed={}", root.join("include/hippt.h").display());

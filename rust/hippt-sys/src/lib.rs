@@ -33,6 +33,12 @@ extern "C" {
     pub fn hippt_render_rgba8(scene: *const hippt_scene, opts: *const hippt_options, out_rgba: *mut u8) -> c_int;
     pub fn hippt_render_accum_f32(scene: *const hippt_scene, opts: *const hippt_options, out_accum: *mut f32,
                                   counters: *mut u64) -> c_int;
+    // one process, several GPUs: sample-range split + one RCCL reduce inside the library
+    pub fn hippt_render_rgba8_multi(scene: *const hippt_scene, opts: *const hippt_options, devices: *const c_int,
+                                    n_devices: c_int, out_rgba: *mut u8) -> c_int;
+    pub fn hippt_render_accum_f32_multi(scene: *const hippt_scene, opts: *const hippt_options, devices: *const c_int,
+                                        n_devices: c_int, out_accum: *mut f32) -> c_int;
+    pub fn hippt_sample_range(total: u32, rank: u32, world: u32, begin: *mut u32, count: *mut u32);
     // resident context + progressive accumulation (long jobs, checkpoints)
     pub fn hippt_create(device: c_int, out_ctx: *mut *mut hippt_context) -> c_int;
     pub fn hippt_destroy(ctx: *mut hippt_context) -> c_int;

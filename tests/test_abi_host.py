@@ -194,3 +194,15 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in txt and "pt_oracle" not in txt and "oracle_lib" not in txt, f
+
+
+def test_sample_range_matches_partition():
+    """hippt_sample_range (the split hippt_render_*_multi uses) == pathtracer_amd.partition.sample_range."""
+    from pathtracer_amd import hip_renderer
+    from pathtracer_amd.partition import sample_range
+    for total in (0, 1, 7, 8, 1024, 4096, 131072, 1000003):
+        for world in (1, 2, 3, 4, 8, 13):
+            got = [hip_renderer.sample_range(total, r, world) for r in range(world)]
+            assert got == [sample_range(total, r, world) for r in range(world)]
+            assert sum(c for _, c in got) == total and got[0][0] == 0
+            assert all(got[r][0] + got[r][1] == got[r + 1][0] for r in range(world - 1))

@@ -109,3 +109,26 @@ def test_context_progressive_api_matches_one_shot():
     img = ctx.resolve(acc, 9)
     ref = hip_renderer.render(s, seed=8)
     assert img.shape == ref.shape and np.abs(img.astype(int) - ref.astype(int)).max() <= 1
+
+
+def test_multi_device_entry_points_with_one_device(tmp_path):
+    """hippt_render_*_multi on the one GPU of this box: the whole path (per-device contexts and threads, librccl opened
+    at run time, communicator, ncclReduce, resolve on devices[0]) with a single rank. The image must equal the
+    one-device entry points' exactly (same kernel, same sample range). More than one rank needs more than one GPU:
+    RCCL refuses a device listed twice, and so does the library."""
+    import subprocess
+    from PIL import Image
+    from pathtracer_amd import Scene, hip_renderer, _abi
+    s = Scene.load(os.path.join(ROOT, "scenes", "scene.example.json"), 96, 64, 12)
+    assert np.array_equal(hip_renderer.render_accum_multi(s, [0], seed=5), hip_renderer.render_accum(s, seed=5))
+    assert np.array_equal(hip_renderer.render_accum_multi(s, [0], 3, 7, seed=5), hip_renderer.render_accum(s, 3, 7, seed=5))
+    assert np.array_equal(hip_renderer.render_multi(s, [0], seed=5), hip_renderer.render(s, seed=5))
+    with pytest.raises(_abi.HipptError, match="listed twice"):
+        hip_renderer.render_multi(s, [0, 0])
+    exe = os.path.join(ROOT, "pathtracer_amd", "bin", "hippt")
+    base = [exe, "--gpu", "--quiet", "--scene", os.path.join(ROOT, "scenes", "scene.example.json"), "--width", "96", "--height", "64",
+            "--samples", "12", "--seed", "5"]
+    for extra, name in ((["--devices", "0"], "m.png"), ([], "s.png")):
+        r = subprocess.run(base + extra + ["--out", str(tmp_path / name)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "m.png")), np.asarray(Image.open(tmp_path / "s.png")))
