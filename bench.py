@@ -24,11 +24,11 @@ sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU (packed f32)
 # HBM bytes of one megakernel launch at 1920x1080 x 1024 spp from the PMC passes in profiles/r01_megakernel_v7_traffic_pmc.txt
-# (FETCH_SIZE 20936 KB, doubled per the gfx950 correction, + WRITE_SIZE 1.629e8 KB). The image itself is 8 sample
+# (FETCH_SIZE 20872 KB, doubled per the gfx950 correction, + WRITE_SIZE 1.633e8 KB). The image itself is 8 sample
 # slices of partial sums, 24.9 MB each (199 MB; pt_add_partials then reads them once); the rest, 167 GB, is
 # write-through of register spills: the kernel holds 11 dwords per lane in scratch across the lights loop of every
 # trip ("spills"). Counters cannot be read inside this process.
-MEGAKERNEL_1080P_TRAFFIC_BYTES = int((2 * 20936.4 + 1.62898e8) * 1024)
+MEGAKERNEL_1080P_TRAFFIC_BYTES = int((2 * 20871.5 + 1.63259e8) * 1024)
 
 
 def cpu_baseline(threads):
