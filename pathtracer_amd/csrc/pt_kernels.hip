@@ -148,12 +148,10 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
         }
 
         constexpr bool kSharedNee = !COUNT && !BVH;
-        ShadeK sk;
         F3 D;
-        if (kind != 0) sk = make_shade(n, -rd, m);
-        if constexpr (kSharedNee) D = tr.direct_light_shared(kind != 0, x, sk, rng, T, my_pl, &wl->nee, wl->acc);
+        if constexpr (kSharedNee) D = tr.direct_light_shared(kind != 0, x, n, -rd, m, rng, T, my_pl, &wl->nee, wl->acc);
         if (kind != 0) {
-            if constexpr (!kSharedNee) D = tr.direct_light(x, sk, rng);
+            if constexpr (!kSharedNee) D = tr.direct_light(x, make_shade(n, -rd, m), rng);
             psum = psum + T * D;  // :285 / :325
             if (kind == 2) {
                 float ct = sample_phase_function(m.aniso, rng.gen());

@@ -169,7 +169,7 @@ struct Tracer {
         uint32_t n = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (n) process_pairs(sh, acc, 0u, n);
     }
-    __device__ __forceinline__ F3 direct_light_shared(bool nee, F3 x, const ShadeK &sk, Rng &rng, F3 T, uint32_t pix,
+    __device__ __forceinline__ F3 direct_light_shared(bool nee, F3 x, F3 n, F3 v, const Mat &m, Rng &rng, F3 T, uint32_t pix,
                                                       NeeShare *sh, float *acc) {
         static_assert(!COUNT && !BVH, "the counting and LBVH kernels use direct_light");
         F3 total = F3{0.0f, 0.0f, 0.0f};
@@ -217,7 +217,7 @@ struct Tracer {
                     object_shadow<Tbl, 4>(tbl, P, h, x, 1e-4f, l, tmax, hit);
 #pragma unroll
                     for (int s = 0; s < 4; ++s)  // a sample that faces away contributes nothing (:50,:55)
-                        if (!hit[s] & (dot(sk.n, l[s]) > 0.0f) & (-dot(l[s], f3(l4)) > 0.0f)) surv |= 1u << s;
+                        if (!hit[s] & (dot(n, l[s]) > 0.0f) & (-dot(l[s], f3(l4)) > 0.0f)) surv |= 1u << s;
                 }
                 const unsigned long long b0 = ballot64((surv & 1u) != 0u), b1 = ballot64((surv & 2u) != 0u),
                                          b2 = ballot64((surv & 4u) != 0u), b3 = ballot64((surv & 8u) != 0u);
@@ -253,6 +253,9 @@ struct Tracer {
             // ONE evaluation site for both cases (two inlined copies could be contracted differently, and a
             // roughness-0.01 highlight amplifies a last-bit difference 1e4 times): surv = samples to evaluate
             if (surv != 0u) {
+                // the shading constants are formed here, per light, rather than carried through the shadow tests in
+                // 10 registers the kernel does not have (5 waves per SIMD: 96 VGPRs)
+                const ShadeK sk = make_shade(n, v, m);
                 F3 contrib = F3{0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
