@@ -24,11 +24,11 @@ sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU (packed f32)
 # HBM bytes of one megakernel launch at 1920x1080 x 1024 spp from the PMC passes in profiles/r01_megakernel_v7_traffic_pmc.txt
-# (FETCH_SIZE 20872 KB, doubled per the gfx950 correction, + WRITE_SIZE 1.633e8 KB). The image itself is 8 sample
-# slices of partial sums, 24.9 MB each (199 MB; pt_add_partials then reads them once); the rest, 167 GB, is
-# write-through of register spills: the kernel holds 11 dwords per lane in scratch across the lights loop of every
-# trip ("spills"). Counters cannot be read inside this process.
-MEGAKERNEL_1080P_TRAFFIC_BYTES = int((2 * 20871.5 + 1.63259e8) * 1024)
+# (FETCH_SIZE 5903 KB, doubled per the gfx950 correction, + WRITE_SIZE 305080 KB). The image itself is 8 sample
+# slices of partial sums, 24.9 MB each (199 MB; pt_add_partials then reads them once); the rest is what the L2
+# evicts of the 4 dwords per lane the kernel keeps in scratch across the lights loop ("Spills").
+# Counters cannot be read inside this process.
+MEGAKERNEL_1080P_TRAFFIC_BYTES = int((2 * 5903.12 + 305080.0) * 1024)
 
 
 def cpu_baseline(threads):
@@ -169,8 +169,8 @@ def main():
                          "note": "algorithmic FLOPs (SURVEY §8d event costs x device event counters of this step) / "
                                  "mean trace-kernel duration from HIP events on the launch stream; the path is "
                                  "VALU-bound (no MFMA); traffic = HBM bytes per launch from the committed PMC passes "
-                                 "(profiles/r01_megakernel_v7_traffic_pmc.txt): 0.2 GB of image partial sums, the rest scratch "
-                                 "write-through of 11 spilled dwords per lane and trip (0.49 TB/s, 6 % of HBM peak)"},
+                                 "(profiles/r01_megakernel_v7_traffic_pmc.txt): 0.2 GB of image partial sums + 0.1 GB of evicted scratch lines, "
+                                 "~160 B per pixel per launch"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
