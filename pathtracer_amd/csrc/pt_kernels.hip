@@ -149,10 +149,12 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
 
         constexpr bool kSharedNee = !COUNT && !BVH;
         F3 D;
-        if constexpr (kSharedNee) D = tr.direct_light_shared(kind != 0, x, n, -rd, m, rng, T, my_pl, &wl->nee, wl->acc);
+        if constexpr (kSharedNee) tr.direct_light_shared(kind != 0, x, n, -rd, m, rng, T, psum, my_pl, &wl->nee, wl->acc);
         if (kind != 0) {
-            if constexpr (!kSharedNee) D = tr.direct_light(x, make_shade(n, -rd, m), rng);
-            psum = psum + T * D;  // :285 / :325
+            if constexpr (!kSharedNee) {
+                D = tr.direct_light(x, make_shade(n, -rd, m), rng);
+                psum = psum + T * D;  // :285 / :325
+            }
             if (kind == 2) {
                 float ct = sample_phase_function(m.aniso, rng.gen());
                 float up = rng.gen();

@@ -141,7 +141,7 @@ struct Tracer {
     // if it arrives) and put on a list in LDS; whenever the list holds 64 rays the wave tests them against the
     // whole scene, one ray per lane, and adds what arrives to the pixel sums `acc` (pixel slot `pix`).
     // Occlusion is an OR over objects, so every ray gets the decision direct_light gives it; only the order of
-    // the f32 additions into the pixel sum differs. Returns the part that is not deferred.
+    // the f32 additions into the pixel sum differs. The part that is not deferred is added to `psum`, the path's sum.
     __device__ __forceinline__ void process_pairs(NeeShare *sh, float *acc, uint32_t first, uint32_t count) {
         const unsigned long long act = ballot64(true);
         const uint32_t n_act = (uint32_t)__popcll(act);
@@ -169,12 +169,11 @@ struct Tracer {
         uint32_t n = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (n) process_pairs(sh, acc, 0u, n);
     }
-    __device__ __forceinline__ F3 direct_light_shared(bool nee, F3 x, F3 n, F3 v, const Mat &m, Rng &rng, F3 T, uint32_t pix,
-                                                      NeeShare *sh, float *acc) {
+    __device__ __forceinline__ void direct_light_shared(bool nee, F3 x, F3 n, F3 v, const Mat &m, Rng &rng, F3 T, F3 &psum,
+                                                        uint32_t pix, NeeShare *sh, float *acc) {
         static_assert(!COUNT && !BVH, "the counting and LBVH kernels use direct_light");
-        F3 total = F3{0.0f, 0.0f, 0.0f};
         const uint32_t n_nee = (uint32_t)__popcll(ballot64(nee));
-        if (n_nee == 0u) return total;
+        if (n_nee == 0u) return;
         // not kept in a register across trips: a lane whose pool item lies outside the image skips the trip
         uint32_t pending = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         uint32_t dummy0 = 0, dummy1 = 0;
@@ -275,7 +274,7 @@ struct Tracer {
                         }
                     }
                 }
-                total = madd(total, contrib, 0.25f);  // :82
+                psum = madd(psum, T * contrib, 0.25f);  // :82 and :285 / :325, straight into the path's sum
             }
             if (hinted_n != 0u) {
                 pending += hinted_n;
@@ -286,7 +285,6 @@ struct Tracer {
                 __hip_atomic_store(&sh->pending, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        return total;
     }
 };
 
