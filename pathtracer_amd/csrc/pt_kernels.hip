@@ -22,6 +22,10 @@ __device__ __forceinline__ void lane_pixel(const Params &P, uint32_t &x, uint32_
     y = ty * 16u + (wave >> 1) * 8u + (lane >> 3);
 }
 
+// 0: every kernel runs the plain lights loop (Tracer::direct_light), for A/B builds (tools/build_variant.sh)
+#ifndef PT_SHARED_NEE
+#define PT_SHARED_NEE 1
+#endif
 // Per-wave scratch in LDS: the 64 pixels' radiance sums and their RNG pixel keys.
 struct WaveLds {
     float acc[64 * 3];
@@ -147,7 +151,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
             }
         }
 
-        constexpr bool kSharedNee = !COUNT && !BVH;
+        constexpr bool kSharedNee = PT_SHARED_NEE && !COUNT && !BVH;
         F3 D;
         if constexpr (kSharedNee) tr.direct_light_shared(kind != 0, x, n, -rd, m, rng, T, psum, my_pl, &wl->nee, wl->acc);
         if (kind != 0) {
@@ -201,7 +205,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
         }
     }
 
-    if constexpr (!COUNT && !BVH) tr.flush_pairs(&wl->nee, wl->acc);
+    if constexpr (PT_SHARED_NEE && !COUNT && !BVH) tr.flush_pairs(&wl->nee, wl->acc);
     __builtin_amdgcn_wave_barrier();
     if (in_image) {
         float *px = accum + (size_t)pixel * 3;
