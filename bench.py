@@ -24,11 +24,11 @@ sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU (packed f32)
 # HBM bytes of one megakernel launch at 1920x1080 x 1024 spp from the PMC passes in profiles/r01_megakernel_v7_traffic_pmc.txt
-# (FETCH_SIZE 5903 KB, doubled per the gfx950 correction, + WRITE_SIZE 305080 KB). The image itself is 8 sample
+# (FETCH_SIZE 3982 KB, doubled per the gfx950 correction, + WRITE_SIZE 275421 KB). The image itself is 8 sample
 # slices of partial sums, 24.9 MB each (199 MB; pt_add_partials then reads them once); the rest is what the L2
 # evicts of the 4 dwords per lane the kernel keeps in scratch across the lights loop ("Spills").
 # Counters cannot be read inside this process.
-MEGAKERNEL_1080P_TRAFFIC_BYTES = int((2 * 5903.12 + 305080.0) * 1024)
+MEGAKERNEL_1080P_TRAFFIC_BYTES = int((2 * 3981.56 + 275421.0) * 1024)
 
 
 def cpu_baseline(threads):
@@ -170,7 +170,7 @@ def main():
                                  "mean trace-kernel duration from HIP events on the launch stream; the path is "
                                  "VALU-bound (no MFMA); traffic = HBM bytes per launch from the committed PMC passes "
                                  "(profiles/r01_megakernel_v7_traffic_pmc.txt): 0.2 GB of image partial sums + 0.1 GB of evicted scratch lines, "
-                                 "~160 B per pixel per launch"},
+                                 "~140 B per pixel per launch"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
