@@ -169,23 +169,22 @@ __global__ __launch_bounds__(256) void wfb_traverse(Bvh bvh, WfQueue Q, const fl
         bool finished = false;
         if (ANY) {
             bool occ = false;
-            if (hl && left < 0) {
-                float t = sphere_t(r, bvh.sph[~left]);
-                occ = occ | ((t > 0.0f) & (t * t < lim));
-                hl = false;
-            }
-            if (hr && right < 0) {
-                float t = sphere_t(r, bvh.sph[~right]);
-                occ = occ | ((t > 0.0f) & (t * t < lim));
-                hr = false;
+            const bool ll = hl && left < 0, rl = hr && right < 0;
+            if (ll || rl) {  // both leaf spheres are fetched at once (one memory latency, not two); a lone leaf twice
+                const int il = ll ? ~left : ~right, ir = rl ? ~right : ~left;
+                const float4 sl = bvh.sph[il], sr = bvh.sph[ir];
+                const float t0 = sphere_t(r, sl), t1 = sphere_t(r, sr);
+                occ = ((t0 > 0.0f) & (t0 * t0 < lim)) | ((t1 > 0.0f) & (t1 * t1 < lim));
+                if (ll) hl = false;
+                if (rl) hr = false;
             }
             if (occ) {
                 occ_out[out_idx] = 1;
                 finished = true;
             }
         } else {
-            auto leaf = [&](int lf) {
-                float t = sphere_t(r, bvh.sph[lf]);
+            auto leaf = [&](int lf, float4 sph) {
+                float t = sphere_t(r, sph);
                 if (t > 0.0f && t <= best_t) {
                     uint32_t ord = __float_as_uint(bvh.aux[lf].z);
                     if (t < best_t || ord < best_ord) {  // renderer.rs:359-361: first minimum in scene order
@@ -195,13 +194,14 @@ __global__ __launch_bounds__(256) void wfb_traverse(Bvh bvh, WfQueue Q, const fl
                     }
                 }
             };
-            if (hl && left < 0) {
-                leaf(~left);
-                hl = false;
-            }
-            if (hr && right < 0) {
-                leaf(~right);
-                hr = false;
+            const bool ll = hl && left < 0, rl = hr && right < 0;
+            if (ll || rl) {  // both leaf spheres are fetched at once (one memory latency, not two)
+                const int il = ll ? ~left : ~right, ir = rl ? ~right : ~left;
+                const float4 sl = bvh.sph[il], sr = bvh.sph[ir];
+                leaf(il, sl);
+                if (ll && rl) leaf(ir, sr);
+                if (ll) hl = false;
+                if (rl) hr = false;
             }
         }
         if (!finished) {
