@@ -1,6 +1,8 @@
 // pt_trace.h — per-vertex building blocks shared by the megakernel (pt_kernels.hip) and the
 // wavefront pipeline (pt_wavefront.hip): closest hit dispatch (table loops or LBVH) and
-// next-event estimation (renderer.rs:19-85).
+// next-event estimation (renderer.rs:19-85) in two forms: Tracer::direct_light, the lights loop as the reference
+// orders it (one lane, one vertex), and Tracer::direct_light_shared, the same work shared across the lanes of a wave
+// (default of the table-scene megakernel; DESIGN.md §3 "Wave-shared NEE").
 #pragma once
 #include "pt_bvh.h"
 #include "pt_device.h"
