@@ -190,6 +190,9 @@ int hippt_render_accum_f32_multi(const hippt_scene *scene, const hippt_options *
  * gpu_renderer.rs:98-102). */
 void hippt_sample_range(uint32_t total, uint32_t rank, uint32_t world,
                         uint32_t *begin, uint32_t *count);
+/* Number of HIP devices this process sees (the reference asks wgpu for one adapter,
+ * gpu_renderer.rs:77-86); 0 with HIPPT_ERR_DEVICE if there is none. */
+int hippt_device_count(int *count);
 
 /* ---- resident-context entry points (bench, multi-GPU, repeated renders) -- */
 

@@ -81,7 +81,7 @@ EXPORTED_SYMBOLS = (
     "hippt_test_diffuse_sample", "hippt_test_glass", "hippt_test_hg", "hippt_test_camera_ray",
     "hippt_test_tonemap", "hippt_test_rng",
     "hippt_render_accum_add_f32", "hippt_resolve_f32", "hippt_checkpoint_save", "hippt_checkpoint_load",
-    "hippt_render_rgba8_multi", "hippt_render_accum_f32_multi", "hippt_sample_range",
+    "hippt_render_rgba8_multi", "hippt_render_accum_f32_multi", "hippt_sample_range", "hippt_device_count",
 )
 
 _lib = None
@@ -128,6 +128,7 @@ def load_library():
     lib.hippt_write_png_rgba8.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
     lib.hippt_render_rgba8_multi.argtypes = [C.POINTER(SceneC), C.POINTER(Options), C.POINTER(C.c_int), C.c_int, C.c_void_p]
     lib.hippt_render_accum_f32_multi.argtypes = [C.POINTER(SceneC), C.POINTER(Options), C.POINTER(C.c_int), C.c_int, C.c_void_p]
+    lib.hippt_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.hippt_sample_range.restype = None
     lib.hippt_sample_range.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     _lib = lib

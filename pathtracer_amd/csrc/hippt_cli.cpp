@@ -12,7 +12,7 @@
 //   --resume           start from PATH if it exists (same size and seed), render the remaining samples
 //   --preview          after every chunk, also write the image of the samples so far to the output path
 // Several GPUs in this process (sample-range split + one RCCL reduce, hippt_render_rgba8_multi):
-//   --devices 0,1,...  the HIP devices to use (not combined with --chunk / --checkpoint)
+//   --devices 0,1,...  the HIP devices to use, or `all` (not combined with --chunk / --checkpoint)
 #include <sys/stat.h>
 
 #include <chrono>
@@ -59,7 +59,14 @@ int main(int argc, char **argv) {
         else if (a == "--resume") resume = true;
         else if (a == "--preview") preview = true;
         else if (a == "--devices") {
-            for (const char *p = next(); *p;) {
+            const char *list = next();
+            if (std::strcmp(list, "all") == 0) {
+                int n = 0;
+                if (hippt_device_count(&n)) die("devices");
+                for (int d = 0; d < n; ++d) devices.push_back(d);
+                list = "";
+            }
+            for (const char *p = list; *p;) {
                 char *end = nullptr;
                 devices.push_back((int)std::strtol(p, &end, 10));
                 if (end == p) {

@@ -152,6 +152,14 @@ int render_reduced(const hippt_scene *scene, const hippt_options *opts, const in
 
 extern "C" {
 
+int hippt_device_count(int *count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (count) *count = e == hipSuccess ? n : 0;
+    if (e != hipSuccess || n == 0) return hippt_set_error(HIPPT_ERR_DEVICE, "no HIP device: %s", hipGetErrorString(e));
+    return HIPPT_OK;
+}
+
 void hippt_sample_range(uint32_t total, uint32_t rank, uint32_t world, uint32_t *begin, uint32_t *count) {
     if (world == 0) world = 1;
     const uint32_t base = total / world, rem = total % world;

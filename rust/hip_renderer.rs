@@ -55,9 +55,12 @@ pub fn render(scene: &Scene) -> RgbaImage {
     };
     let opts = hippt_options { seed: rand::random(), ..Default::default() };
     let mut rgba = vec![0u8; (width * height * 4) as usize];
-    // HIPPT_DEVICES=0,1,...,7 renders on several GPUs of the node (sample-range split, RCCL reduce in the library)
-    let devices: Vec<i32> = std::env::var("HIPPT_DEVICES").ok()
-        .map(|s| s.split(',').filter_map(|d| d.trim().parse().ok()).collect()).unwrap_or_default();
+    // HIPPT_DEVICES=0,1,...,7 (or `all`) renders on several GPUs of the node (sample-range split, RCCL reduce in the library)
+    let devices: Vec<i32> = match std::env::var("HIPPT_DEVICES").ok().as_deref() {
+        Some("all") => { let mut n = 0; unsafe { hippt_device_count(&mut n) }; (0..n).collect() }
+        Some(s) => s.split(',').filter_map(|d| d.trim().parse().ok()).collect(),
+        None => Vec::new(),
+    };
     let rc = if devices.is_empty() {
         unsafe { hippt_render_rgba8(&c_scene, &opts, rgba.as_mut_ptr()) }
     } else {

@@ -39,6 +39,7 @@ extern "C" {
     pub fn hippt_render_accum_f32_multi(scene: *const hippt_scene, opts: *const hippt_options, devices: *const c_int,
                                         n_devices: c_int, out_accum: *mut f32) -> c_int;
     pub fn hippt_sample_range(total: u32, rank: u32, world: u32, begin: *mut u32, count: *mut u32);
+    pub fn hippt_device_count(count: *mut c_int) -> c_int;
     // resident context + progressive accumulation (long jobs, checkpoints)
     pub fn hippt_create(device: c_int, out_ctx: *mut *mut hippt_context) -> c_int;
     pub fn hippt_destroy(ctx: *mut hippt_context) -> c_int;
