@@ -128,3 +128,60 @@ def test_tables_near_the_lds_budget(oracle):
             g = got[ys.ravel(), xs.ravel()].astype(np.float64)
             r = np.abs(g - ref).max(axis=1) / np.maximum(np.abs(ref).max(axis=1), 4e-3)
             assert np.quantile(r, 0.5) < 2e-6 and np.quantile(r, 0.9) < 1e-3, (n_pl, np.quantile(r, [0.5, 0.9, 0.99]))
+
+
+def _occluder_scene(kind, w=104, h=72, spp=8):
+    """Matte floor lit by rectangles above it, with occluders arranged to drive the wave-shared lights loop
+    (Tracer::direct_light_shared) through each of its cases."""
+    from pathtracer_amd import Scene
+    s = Scene()
+    s.width, s.height, s.samples = w, h, spp
+    floor = s.add_material((0.8, 0.8, 0.8), roughness=0.9)
+    grey = s.add_material((0.5, 0.5, 0.6), roughness=0.7)
+    metal = s.add_material((0.9, 0.7, 0.4), metallic=1.0, roughness=0.3)
+    s.add_plane((0, -1, 6), (8, 0, 0), (0, 0, -8), floor)          # floor, normal +y
+    s.add_sphere((-1.2, -0.3, 5.0), 0.7, metal)
+    s.add_sphere((1.3, -0.4, 6.0), 0.6, grey)
+    if kind == "lid":  # one slab hides the first light from everything: every wave-trip ends with no ray left
+        s.add_plane((0, 2.0, 6), (6, 0, 0), (0, 0, -6), grey)
+        s.add_light((0, 3.0, 6), (-1, 0, 0), (0, 0, -1), (60, 60, 60))
+        s.add_light((0, 1.5, 2), (-1, 0, 0), (0, 0.3, -1), (25, 25, 25))
+    elif kind == "half":  # a slab over half of the floor: along its shadow edge a few rays per wave survive the remembered occluder
+        s.add_plane((-2.0, 1.5, 6), (2.0, 0, 0), (0, 0, -6), grey)
+        s.add_light((0, 3.0, 6), (-1.5, 0, 0), (0, 0, -1.5), (60, 60, 60))
+    elif kind == "slats":  # many equal slats: no occluder dominates for long, the hint is learnt, overflows and is dropped again
+        for i in range(9):
+            s.add_plane((-3.2 + 0.8 * i, 1.5, 6), (0.25, 0, 0), (0, 0, -6), grey)
+        s.add_light((0, 3.0, 6), (-2, 0, 0), (0, 0, -2), (60, 60, 60))
+        s.add_light((3, 2.5, 3), (0, -1, 0), (0, 0, -1), (30, 30, 30))
+    else:  # "many": 10 lights, more than the wave keeps hints for, each behind its own small slab
+        for i in range(10):
+            x = -3.6 + 0.8 * i
+            s.add_plane((x, 1.6, 6), (0.5, 0, 0), (0, 0, -1.5), grey)
+            s.add_light((x, 2.6, 6), (-0.3, 0, 0), (0, 0, -0.3), (40, 40, 40))
+    s.set_camera((0, 1.2, -2.5), (0, -0.3, 5.5), (0, 1, 0), 50.0, 0.0)
+    return s
+
+
+@pytest.mark.parametrize("kind", ["lid", "half", "slats", "many"])
+def test_wave_shared_lights_loop_cases(oracle, kind):
+    """The default kernel (remembered occluders, deferred shadow rays) against the oracle, path sums per pixel, on
+    scenes built to hit: no survivor at all, a few survivors per wave, overflowing lists and dropped hints, more lights
+    than hint slots. Also against the counting kernel, which runs the plain lights loop."""
+    from pathtracer_amd import hip_renderer
+    s = _occluder_scene(kind)
+    acc_o = oracle.render_accum(s, seed=3)
+    acc_c, _ = hip_renderer.render_accum(s, seed=3, counters=True)
+    acc_d = hip_renderer.render_accum(s, seed=3)
+    assert acc_o.sum() > 0
+    for acc in (acc_c, acc_d):
+        r = np.abs(acc.astype(np.float64) - acc_o).max(axis=2) / np.maximum(np.abs(acc_o).max(axis=2), 1e-3 * s.samples)
+        assert np.quantile(r, 0.5) < 2e-6 and np.quantile(r, 0.95) < 1e-3, (kind, np.quantile(r, [0.5, 0.95, 0.99]))
+        assert abs(acc.sum(dtype=np.float64) - acc_o.sum(dtype=np.float64)) <= 2e-3 * acc_o.sum(dtype=np.float64)
+    # chunked == one-shot (which rays are deferred depends on the wave's history, their outcome must not)
+    ctx = hip_renderer.Context(0)
+    ctx.set_scene(s)
+    acc = np.zeros_like(acc_d)
+    for b, c in ((0, 3), (3, 1), (4, 4)):
+        ctx.render_accum_add(acc, b, c, seed=3)
+    assert np.allclose(acc, acc_d, rtol=2e-6, atol=1e-6)
