@@ -172,7 +172,7 @@ def main():
                                  "(profiles/r01_megakernel_v7_traffic_pmc.txt): 0.2 GB of image partial sums + 0.1 GB of evicted scratch lines, "
                                  "~140 B per pixel per launch"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: the other ranks would wait at the barrier
             out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
     if world > 1:
         dist.barrier()
