@@ -69,8 +69,8 @@ __device__ __forceinline__ float box_entry(const BoxRay &b, F3 lo, F3 hi, float 
 __device__ __forceinline__ void bvh_closest(const Bvh &B, const RayK &r, float &best_t, int &best_leaf,
                                             uint32_t &best_ord, uint32_t *stack, uint32_t stride, uint32_t &n_tests) {
     BoxRay br = make_box_ray(r.ro, r.rd);
-    auto leaf = [&](int lf) {
-        float t = sphere_t(r, B.sph[lf]);
+    auto leaf = [&](int lf, float4 sph) {
+        float t = sphere_t(r, sph);
         ++n_tests;
         if (t > 0.0f && t <= best_t) {
             uint32_t ord = __float_as_uint(B.aux[lf].z);
@@ -89,13 +89,14 @@ __device__ __forceinline__ void bvh_closest(const Bvh &B, const RayK &r, float &
         float tl = box_entry(br, nb.llo, nb.lhi, best_t);
         float tr = box_entry(br, nb.rlo, nb.rhi, best_t);
         bool hl = tl < __builtin_inff(), hr = tr < __builtin_inff();
-        if (hl && left < 0) {
-            leaf(~left);
-            hl = false;
-        }
-        if (hr && right < 0) {
-            leaf(~right);
-            hr = false;
+        const bool ll = hl && left < 0, rl = hr && right < 0;
+        if (ll || rl) {  // both leaf spheres are fetched at once (one memory latency, not two)
+            const int il = ll ? ~left : ~right, ir = rl ? ~right : ~left;
+            const float4 sl = B.sph[il], sr = B.sph[ir];
+            leaf(il, sl);
+            if (ll && rl) leaf(ir, sr);
+            if (ll) hl = false;
+            if (rl) hr = false;
         }
         if (hl && hr) {
             bool lfirst = tl <= tr;
@@ -124,17 +125,15 @@ __device__ __forceinline__ bool bvh_any(const Bvh &B, const RayK &r, float lim, 
         int left = nb.left, right = nb.right;
         bool hl = box_entry(br, nb.llo, nb.lhi, t_max) < __builtin_inff();
         bool hr = box_entry(br, nb.rlo, nb.rhi, t_max) < __builtin_inff();
-        if (hl && left < 0) {
-            float t = sphere_t(r, B.sph[~left]);
-            ++n_tests;
-            occ = occ | ((t > 0.0f) & (t * t < lim));
-            hl = false;
-        }
-        if (hr && right < 0) {
-            float t = sphere_t(r, B.sph[~right]);
-            ++n_tests;
-            occ = occ | ((t > 0.0f) & (t * t < lim));
-            hr = false;
+        const bool ll = hl && left < 0, rl = hr && right < 0;
+        if (ll || rl) {  // both leaf spheres at once; a lone leaf is read twice and counted once
+            const int il = ll ? ~left : ~right, ir = rl ? ~right : ~left;
+            const float4 sl = B.sph[il], sr = B.sph[ir];
+            const float t0 = sphere_t(r, sl), t1 = sphere_t(r, sr);
+            n_tests += (ll && rl) ? 2u : 1u;
+            occ = occ | ((t0 > 0.0f) & (t0 * t0 < lim)) | ((t1 > 0.0f) & (t1 * t1 < lim));
+            if (ll) hl = false;
+            if (rl) hr = false;
         }
         if (occ) break;
         if (hl && hr) {
