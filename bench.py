@@ -1,21 +1,34 @@
 #!/usr/bin/env python3
 """bench.py — BASELINE.json's metric: Mpaths/s (node) at 1080p; % of FP32 VALU peak.
 
-A "step" is one pass of the hot path over the C2 workload: scene.example.json at
-1920x1080, 1024 samples per pixel per GPU, max depth 5 (BASELINE configs[1]).
-With N GPUs (one process per GPU, torch.distributed/RCCL) rank r renders the
-global sample range [1024 r, 1024 (r+1)) of a 1024 N spp image (weak scaling,
-sample-range split of SURVEY.md §8e); the per-GPU f32 radiance accumulators are
-summed on rank 0 with one RCCL reduce and resolved (average, ACES, gamma, u8)
-there, all inside the timed region. Scene tables and accumulators are resident
-in HBM before the timed region starts.
+A "step" is one pass of the hot path over the workload of --config (default C2 = BASELINE
+configs[1]: scene.example.json at 1920x1080, 1024 samples per pixel, max depth 5).
+
+N GPUs, one process per GPU (torch.distributed, backend nccl = RCCL). The default is the
+north star's split — STRONG scaling: the image's --spp samples are cut into N contiguous
+sample ranges (pathtracer_amd.partition.sample_range; the reference cuts its samples into
+dispatches and sums them on the host, src/gpu_renderer.rs:94-102,175-179), rank r renders
+all pixels for range r, the per-GPU f32 radiance accumulators are summed on rank 0 with ONE
+RCCL reduce and resolved there (average, ACES, gamma, u8), all inside the timed region.
+`--scaling weak` keeps --spp per GPU instead (an N * spp image). Scene tables and
+accumulators are resident in HBM before the timed region starts.
+
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself
+(N child processes, before this process touches a GPU) and exits with their status; under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks are already
+there and each process is one of them.
+
+Every rank's work of one step runs on ONE explicit HIP stream (accumulator clear, trace
+kernels, RCCL reduce, resolve), so the steps are ordered among themselves and the timed
+region is the render -> reduce -> resolve chain.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,12 +36,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU (packed f32)
-# HBM bytes of one megakernel launch at 1920x1080 x 1024 spp from the PMC passes in profiles/r01_megakernel_v7_traffic_pmc.txt
-# (FETCH_SIZE 3982 KB, doubled per the gfx950 correction, + WRITE_SIZE 275421 KB). The image itself is 8 sample
-# slices of partial sums, 24.9 MB each (199 MB; pt_add_partials then reads them once); the rest is what the L2
-# evicts of the 4 dwords per lane the kernel keeps in scratch across the lights loop ("Spills").
-# Counters cannot be read inside this process.
-MEGAKERNEL_1080P_TRAFFIC_BYTES = int((2 * 3981.56 + 275421.0) * 1024)
+L2_PEAK_TBS = 34.5             # MI355X_MICROARCH.md "L2 (per XCD)": aggregate over the 8 XCDs
+HBM_PEAK_TBS = 8.0
+
+# Workloads (BASELINE.json configs): width, height, samples per pixel of one step, scene.
+CONFIGS = {
+    "c2": (1920, 1080, 1024, "scene.example.json"),
+    "c3": (1920, 1080, 4096, "glass_fog.json"),
+    "c4": (1920, 1080, 256, None),   # synthetic_spheres(100000, 0x5EED), LBVH
+    # the showcase job is 131072 spp (4.3 T paths, ~11 min on one GPU): a step is one 128-spp chunk of it
+    "c5": (7680, 4320, 128, "scene.example.json"),
+}
+
+# Counter figures that cannot be read inside this process (rocprofv3 --pmc runs of this same command, kept under
+# profiles/). Keyed by (config, width, height, spp per launch, flags, max_depth); anything else reports null.
+PMC_INDEX = os.path.join(ROOT, "profiles", "pmc_index.json")
+
+
+def pmc_lookup(config, W, H, spp_launch, flags, max_depth):
+    try:
+        with open(PMC_INDEX) as f:
+            idx = json.load(f)
+    except OSError:
+        return None
+    return idx.get(f"{config}:{W}x{H}:{spp_launch}spp:flags{flags}:depth{max_depth}")
 
 
 def cpu_baseline(threads):
@@ -43,33 +74,111 @@ def cpu_baseline(threads):
     orc.render_accum(s, 0, spp, seed=0, threads=threads)
     dt = time.perf_counter() - t0
     return {"value": round(1920 * 1080 * spp / dt / 1e6, 4), "unit": "Mpaths/s", "cores": threads, "kind": "port",
-            "sample": f"scene.example.json 1920x1080 at {spp} spp (same scene/size as the step, 1/16 of its samples), "
-                      f"{dt:.1f} s; C++ restatement of src/renderer.rs, one task per row as src/main.rs:126"}
+            "host_cores_online": os.cpu_count(),
+            "sample": f"scene.example.json 1920x1080 at {spp} spp (C2's scene and size, 1/16 of its samples; not C1 + "
+                      f"1080p x 16 as SURVEY §8d sketched), {dt:.1f} s on {threads} threads (the GPU box's CPU share); "
+                      f"C++ restatement of src/renderer.rs, one task per row as src/main.rs:126"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=1024, help="samples per pixel per GPU per step")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None,
+                    help="samples per pixel of the image (strong scaling) or per GPU (weak); default: the config's")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--scene", default=None, help="scene.json path (overrides --config's scene)")
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"],
-                    help="BASELINE config: c2 scene.example (default, the headline), c3 glass+fog, c4 100k spheres + LBVH")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
+                    help="BASELINE config: c2 scene.example (default, the headline), c3 glass+fog, c4 100k spheres + LBVH, "
+                         "c5 scene.example at 7680x4320")
     ap.add_argument("--max-depth", type=int, default=5)
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: gloo ranks exchange their sample counts instead of rendering (launcher / split / reduce check)")
+    return ap.parse_args(argv)
 
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """Starts n ranks of this script (one per GPU) and waits for them. Runs before anything touches a GPU: the
+    parent never initialises HIP and never replaces itself, the ranks are fresh child processes."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with status {code}; stopping the other ranks", file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()  # exactly the children started above
+        time.sleep(0.05)
+    return rc
+
+
+def dry_run(args, rank, world):
+    """Launcher / partition / reduce logic without a GPU: every rank contributes its sample count per element."""
     import torch
     import torch.distributed as dist
-    from pathtracer_amd import Scene, _abi, flops, hip_renderer
+    from pathtracer_amd.partition import sample_range
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    spp = args.spp or CONFIGS[args.config][2]
+    total = spp if args.scaling == "strong" else spp * world
+    b, c = sample_range(total, rank, world)
+    acc = torch.full((16,), float(c), dtype=torch.float32)
+    ranges = [None] * world
+    if world > 1:
+        dist.reduce(acc, dst=0)
+        dist.all_gather_object(ranges, (b, c))
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ranges = [(b, c)]
+    if rank == 0:
+        assert float(acc[0]) == float(total), (acc, total)
+        print(json.dumps({"dry_run": True, "n_gpus": world, "world_size": world, "scaling": args.scaling,
+                          "spp_total": total, "sample_ranges": ranges}), flush=True)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; running {world} rank(s)", file=sys.stderr)
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import Scene, _abi, flops, hip_renderer
+    from pathtracer_amd.partition import sample_range
+
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
@@ -77,30 +186,34 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    W, H, SPP = args.width, args.height, args.spp
+    cW, cH, cS, cscene = CONFIGS[args.config]
+    W, H = args.width or cW, args.height or cH
+    spp_arg = args.spp or cS
+    total_spp = spp_arg if args.scaling == "strong" else spp_arg * world
+    s0, cnt = sample_range(total_spp, rank, world)
     if args.scene:
-        scene, scene_name = Scene.load(args.scene, W, H, SPP * world), os.path.basename(args.scene)
+        scene, scene_name = Scene.load(args.scene, W, H, total_spp), os.path.basename(args.scene)
     elif args.config == "c4":
         from pathtracer_amd.synthetic import synthetic_spheres
-        scene, scene_name = synthetic_spheres(100000, 0x5EED, W, H, SPP * world), "synthetic_spheres(n=100000, seed=0x5EED), LBVH"
+        scene, scene_name = synthetic_spheres(100000, 0x5EED, W, H, total_spp), "synthetic_spheres(n=100000, seed=0x5EED), LBVH"
     else:
-        scene_name = {"c2": "scene.example.json", "c3": "glass_fog.json"}[args.config]
-        scene = Scene.load(os.path.join(ROOT, "scenes", scene_name), W, H, SPP * world)
+        scene, scene_name = Scene.load(os.path.join(ROOT, "scenes", cscene), W, H, total_spp), cscene
     ctx = hip_renderer.Context(local_rank)
     ctx.set_scene(scene)
     accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
     rgba = torch.zeros(H * W * 4, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    s0 = rank * SPP
+    stream = torch.cuda.Stream(dev)  # a real (non-NULL) stream: NULL would mean "the context's own stream" to the C ABI
+    assert stream.cuda_stream != 0
 
     def step(flags=args.flags):
-        accum.zero_()
-        ctx.render_accum_device(accum.data_ptr(), s0, SPP, seed=0, max_depth=args.max_depth, flags=flags,
-                                stream=stream.cuda_stream)
-        if world > 1:
-            dist.reduce(accum, dst=0)  # RCCL sum of the per-GPU accumulators
-        if rank == 0:
-            ctx.resolve_device(accum.data_ptr(), SPP * world, rgba.data_ptr(), stream=stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            accum.zero_()
+            ctx.render_accum_device(accum.data_ptr(), s0, cnt, seed=0, max_depth=args.max_depth, flags=flags,
+                                    stream=stream.cuda_stream)
+            if world > 1:
+                dist.reduce(accum, dst=0)  # RCCL sum of the per-GPU accumulators, queued behind the kernels
+            if rank == 0:
+                ctx.resolve_device(accum.data_ptr(), total_spp, rgba.data_ptr(), stream=stream.cuda_stream)
 
     def sync():
         if world > 1:
@@ -116,62 +229,89 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
+    devices = [local_rank]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([local_rank], dtype=torch.int64, device=dev))
+        devices = [int(x.item()) for x in ids]
     kernel_ms, launches = ctx.kernel_time_ms()
-
-    # image sanity on rank 0: finite, non-trivial
-    if rank == 0:
-        mean_rad = float(accum.mean().item()) / (SPP * world)
-        assert mean_rad == mean_rad and mean_rad > 0.0, "image is empty or NaN"
 
     out = None
     if rank == 0:
-        # event counts of exactly this rank's step (counting variant of the megakernel, untimed; the wavefront
-        # variant traces the same paths, so its events are the same)
-        accum.zero_()
-        ctx.render_accum_device(accum.data_ptr(), s0, SPP, seed=0, max_depth=args.max_depth,
-                                flags=(args.flags & ~_abi.FLAG_WAVEFRONT) | _abi.FLAG_COUNTERS,
-                                stream=stream.cuda_stream)
+        # image sanity: finite, non-trivial, and exactly ONE step's worth of samples in the accumulator
+        mean_rad = float(accum.mean().item()) / total_spp
+        assert mean_rad == mean_rad and mean_rad > 0.0, "image is empty or NaN"
+        step_sum = float(accum.double().sum().item())
+
+        # event counts of exactly this rank's share of a step (counting variant of the megakernel, untimed; the queue
+        # variants trace the same paths, so the path-level events are the same — for LBVH scenes the sphere-test
+        # counts are those of the BVH megakernel's traversal order, see "flop_note")
+        with torch.cuda.stream(stream):
+            accum.zero_()
+            ctx.render_accum_device(accum.data_ptr(), s0, cnt, seed=0, max_depth=args.max_depth,
+                                    flags=(args.flags & ~_abi.FLAG_WAVEFRONT) | _abi.FLAG_COUNTERS,
+                                    stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
+        if world == 1:  # the counting kernel renders the same samples: a step that ran twice, or not at all, shows here
+            count_sum = float(accum.double().sum().item())
+            assert abs(step_sum - count_sum) <= 2e-3 * abs(count_sum), (step_sum, count_sum)
         cn = ctx.read_counters()
         ctx.kernel_time_ms()
         fl = flops.algorithmic_flops(cn, len(scene.lights))
-        paths_step = W * H * SPP * world
+        paths_step = W * H * total_spp
         ms_per_step = elapsed / args.steps * 1e3
         k_ms = kernel_ms / max(launches, 1)
-        flop_per_launch = fl / (launches / args.steps)
+        launches_per_step = max(launches // max(args.steps, 1), 1)
+        flop_per_launch = fl / launches_per_step
         achieved = flop_per_launch / (k_ms * 1e-3) / 1e12
+        lbvh = len(scene.spheres) >= 64 and not args.flags & _abi.FLAG_NO_BVH
+        kernel = (("wavefront+lbvh" if not args.flags & _abi.FLAG_MEGAKERNEL else "megakernel+lbvh") if lbvh else
+                  ("wavefront" if args.flags & _abi.FLAG_WAVEFRONT else "megakernel"))
+        pmc = pmc_lookup(args.config if not args.scene else "scene", W, H, cnt // launches_per_step, args.flags, args.max_depth)
         out = {
             "metric": "Mpaths/s (node) at 1080p; % of FP32 VALU peak",
             "value": round(paths_step / (elapsed / args.steps) / 1e6, 2),
             "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config.upper()}: {scene_name} {W}x{H}, {SPP} spp per GPU ({SPP * world} spp image), "
-                                   f"max_depth {args.max_depth}, seed 0",
-                       "parallelism": f"sample-range split over {world} GPU(s), one RCCL reduce" if world > 1 else "1 GPU",
-                       "kernel": ("wavefront+lbvh" if not args.flags & _abi.FLAG_MEGAKERNEL else "megakernel+lbvh")
-                                 if len(scene.spheres) >= 64 and not args.flags & _abi.FLAG_NO_BVH else
-                                 ("wavefront" if args.flags & _abi.FLAG_WAVEFRONT else "megakernel"),
-                       "tables": "global" if (args.flags & _abi.FLAG_TABLES_GLOBAL or len(scene.spheres) >= 64) else "lds"},
-            "mrays_per_s": round(flops.rays(cn) * world / (elapsed / args.steps) / 1e6, 1),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32",
+            "data": ("synthetic (generated 100k-sphere scene)" if args.config == "c4" and not args.scene else
+                     f"{scene_name} (the reference's example scene; no external data)"),
+            "world_size": dist.get_world_size() if world > 1 else 1,
+            "devices": devices,
+            "config": {"workload": f"{args.config.upper()}: {scene_name} {W}x{H}, {total_spp} spp image, "
+                                   f"{cnt} spp on rank 0, max_depth {args.max_depth}, seed 0",
+                       "parallelism": (f"sample-range split over {world} GPUs ({args.scaling} scaling), one RCCL reduce"
+                                       if world > 1 else "1 GPU"),
+                       "kernel": kernel,
+                       "tables": "global" if (args.flags & _abi.FLAG_TABLES_GLOBAL or lbvh) else "lds"},
+            "mrays_per_s": round(flops.rays(cn) * (paths_step / max(cn["paths"], 1)) / (elapsed / args.steps) / 1e6, 1),
             "pct_fp32_valu_peak": round(100.0 * achieved / FP32_VALU_PEAK_TFLOPS, 2),
             "flop_per_path": round(fl / cn["paths"], 1),
             "roofline": {"bound": "valu_fp32", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
-                         "traffic": MEGAKERNEL_1080P_TRAFFIC_BYTES if (W, H, args.spp, args.flags, args.config) == (1920, 1080, 1024, 0, "c2") and not args.scene else None,
-                         "kernel_ms": round(k_ms, 3), "launches_per_step": launches // args.steps,
-                         "note": "algorithmic FLOPs (SURVEY §8d event costs x device event counters of this step) / "
-                                 "mean trace-kernel duration from HIP events on the launch stream; the path is "
-                                 "VALU-bound (no MFMA); traffic = HBM bytes per launch from the committed PMC passes "
-                                 "(profiles/r01_megakernel_v7_traffic_pmc.txt): 0.2 GB of image partial sums + 0.1 GB of evicted scratch lines, "
-                                 "~140 B per pixel per launch"},
+                         "traffic": None,
+                         "kernel_ms": round(k_ms, 3), "launches_per_step": launches_per_step,
+                         "note": "rank 0's GPU: algorithmic FLOPs (SURVEY §8d event costs x device event counters of this "
+                                 "rank's share of a step) / mean trace-kernel duration from HIP events on the launch stream; "
+                                 "the path is VALU-bound (no MFMA)"},
         }
+        if pmc:  # figures from committed rocprofv3 --pmc passes of this command: NOT measured in this run
+            r = out["roofline"]
+            r["traffic"] = pmc.get("traffic_bytes")
+            r["traffic_source"] = f"{pmc.get('source')} (rocprofv3 --pmc pass of this command on an earlier run; not measured in this run)"
+            for k in ("hw_flop_frac", "lanes_active", "l2_hit_rate"):
+                if k in pmc:
+                    r[k] = pmc[k]
+            if "note" in pmc:
+                r["pmc_note"] = pmc["note"]
+        if lbvh and kernel == "wavefront+lbvh":
+            out["flop_note"] = ("event counts come from the BVH megakernel (HIPPT_FLAG_COUNTERS); its traversal visits "
+                                "spheres in another order than the queue kernels, so sphere-test counts differ slightly")
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: the other ranks would wait at the barrier
             out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
     if world > 1:

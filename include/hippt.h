@@ -121,6 +121,10 @@ typedef struct hippt_scene {
                                         (scalar loads) instead of staging in LDS */
 #define HIPPT_FLAG_NO_SLICES 64u  /* one block renders a tile's whole sample range (no partial-sum slices) */
 #define HIPPT_FLAG_MEGAKERNEL 32u /* force the one-kernel variant (the default for scenes without LBVH) */
+#define HIPPT_FLAG_LOCAL_REDUCE 128u /* hippt_render_*_multi only: add the ranks' accumulators up on devices[0] with
+                                        peer copies + a device add kernel instead of RCCL; a device may then be
+                                        listed more than once (several ranks share it: a one-GPU box can rehearse the
+                                        split, the per-rank contexts / threads / streams and the sum) */
 
 typedef struct hippt_options {
     uint32_t sample_begin; /* first global sample index rendered by this call */
@@ -182,7 +186,8 @@ int hippt_render_accum_f32(const hippt_scene *scene, const hippt_options *opts,
  * beyond the order of the f32 additions. opts->device is ignored. */
 int hippt_render_rgba8_multi(const hippt_scene *scene, const hippt_options *opts,
                              const int *devices, int n_devices, uint8_t *out_rgba);
-/* Radiance sums of opts' sample range (the whole image if its count is 0). */
+/* Radiance sums of opts' sample range; sample_count 0 = from sample_begin to scene->samples, as the one-device
+ * entry points read it. */
 int hippt_render_accum_f32_multi(const hippt_scene *scene, const hippt_options *opts,
                                  const int *devices, int n_devices, float *out_accum);
 /* Rank's share of `total` samples over `world` ranks: contiguous, counts differ by at
@@ -203,7 +208,10 @@ int hippt_create(int device, hippt_context **out_ctx);
 int hippt_destroy(hippt_context *ctx);
 
 /* Copies the scene tables to device memory (replaces the per-dispatch buffer
- * creation of src/gpu_renderer.rs:243-275; done once, not per dispatch). */
+ * creation of src/gpu_renderer.rs:243-275; done once, not per dispatch) and builds the LBVH for scenes with
+ * >= 64 spheres. If only the LBVH build fails (tree deeper than the traversal stack, out of memory) the call
+ * returns that error but the scene IS set: renders with HIPPT_FLAG_NO_BVH (brute-force loops) work, renders
+ * without it repeat the error. Any other failure leaves the context without a scene. */
 int hippt_set_scene(hippt_context *ctx, const hippt_scene *scene);
 
 /* Launches the trace kernels for samples [sample_begin, sample_begin+count)
@@ -272,6 +280,11 @@ const hippt_scene *hippt_scene_get(const hippt_scene_file *f);
 int hippt_scene_set_render(hippt_scene_file *f, uint32_t width, uint32_t height,
                            uint32_t samples);
 void hippt_scene_free(hippt_scene_file *f);
+/* The camera / object / light dump that main() prints before it renders (src/main.rs:60-87), byte for byte:
+ * position / look_at / up as Rust `{:?}` of Vec3 (shortest round-trip digits, "1.0" for integral values),
+ * fov `{:.2}`, aspect / aperture / autofocus `{:.4}`, objects with their names, lights. Writes at most cap-1
+ * bytes + NUL to out (may be NULL) and returns the length of the whole text, -1 if f is NULL. */
+int hippt_scene_dump(const hippt_scene_file *f, char *out, size_t cap);
 
 /* Camera basis from pos/look_at/up/fov(deg) as src/main.rs:41-51. */
 void hippt_camera_basis(const float pos[3], const float look_at[3], const float up[3],
@@ -304,6 +317,12 @@ int hippt_test_intersect_bvh(const hippt_scene *scene, uint32_t n, const float *
  * ro + t*rd with UNIT-length rd (the routine the NEE kernel uses, origin offset folded out). */
 int hippt_test_occluded(const hippt_scene *scene, uint32_t n, const float *ro,
                         const float *rd, const float *dist2, uint8_t *out, int device);
+/* The same test as next-event estimation runs it (src/renderer.rs:44-46): shading point x, UNIT direction l towards
+ * the light sample, dist2 = |light point - x|^2; the shadow ray starts at x + l*1e-4 and is occluded iff some object
+ * has t > 0 (plane: t > 1e-4) and t*t < dist2*0.999. Runs the production 4-rays-per-lane routine with the origin
+ * offset folded into its arithmetic. out: bit 0 = occluded, bit 1 = the four slots of the lane disagreed (a bug). */
+int hippt_test_shadow_nee(const hippt_scene *scene, uint32_t n, const float *x, const float *l,
+                          const float *dist2, uint8_t *out, int device);
 /* one unoccluded light sample, src/renderer.rs:49-77. mat = n x 8 floats in
  * hippt_material order; light = one hippt_light. out = rgb contribution
  * (before the 1/SHADOW_SAMPLES average). */

@@ -17,6 +17,7 @@ FLAG_NO_BVH = 8
 FLAG_TABLES_GLOBAL = 16
 FLAG_MEGAKERNEL = 32
 FLAG_NO_SLICES = 64
+FLAG_LOCAL_REDUCE = 128
 
 COUNTER_NAMES = (
     "paths", "extend_rays", "extend_hits", "shadow_rays", "shadow_sphere_tests",
@@ -82,6 +83,7 @@ EXPORTED_SYMBOLS = (
     "hippt_test_tonemap", "hippt_test_rng",
     "hippt_render_accum_add_f32", "hippt_resolve_f32", "hippt_checkpoint_save", "hippt_checkpoint_load",
     "hippt_render_rgba8_multi", "hippt_render_accum_f32_multi", "hippt_sample_range", "hippt_device_count",
+    "hippt_scene_dump", "hippt_test_shadow_nee",
 )
 
 _lib = None
@@ -91,11 +93,34 @@ class HipptError(RuntimeError):
     """Non-zero status from the C ABI (the reference panics via `expect`)."""
 
 
+def _one_hip_runtime():
+    """One HIP runtime per process. libhippt.so needs `libamdhip64.so.7` and finds the system ROCm's; a PyTorch-ROCm
+    wheel ships its OWN copy (same SONAME) and asks for it as `libamdhip64.so`. If PyTorch is imported first, libhippt
+    binds to PyTorch's copy by SONAME and all is well; the other way round the loader takes PyTorch's request for a
+    different name and the process ends up with two runtimes, in which a torch stream or device pointer handed to
+    libhippt belongs to the wrong one (seen as an abort inside hippt_render_accum_device). So when PyTorch is
+    installed but not imported yet, its copy of the runtime is loaded first, and both libraries share it."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load_library():
     """Loads pathtracer_amd/lib/libhippt.so (built by __graft_entry__.build())."""
     global _lib
     if _lib is not None:
         return _lib
+    _one_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise HipptError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -129,6 +154,12 @@ def load_library():
     lib.hippt_render_rgba8_multi.argtypes = [C.POINTER(SceneC), C.POINTER(Options), C.POINTER(C.c_int), C.c_int, C.c_void_p]
     lib.hippt_render_accum_f32_multi.argtypes = [C.POINTER(SceneC), C.POINTER(Options), C.POINTER(C.c_int), C.c_int, C.c_void_p]
     lib.hippt_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.hippt_scene_dump.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.hippt_render_accum_add_f32.argtypes = [C.c_void_p, C.POINTER(Options), C.c_void_p]
+    lib.hippt_resolve_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.hippt_checkpoint_save.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.hippt_checkpoint_load.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_uint32)]
     lib.hippt_sample_range.restype = None
     lib.hippt_sample_range.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     _lib = lib

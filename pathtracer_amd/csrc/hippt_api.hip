@@ -53,6 +53,17 @@ const size_t kMaxLdsBlob = 64 * 1024 - pt::megakernel_static_lds();
 // Sphere count from which hippt_set_scene builds the LBVH (brute force wins below).
 constexpr uint32_t kBvhMinSpheres = 64;
 
+// Sample slices of one megakernel launch of `c` samples per pixel: enough blocks for ~50 rounds of the chip's ~1 300
+// resident blocks (measured: 3 slices +3.4 %, 8 slices +4.6 %, 16 no more), at most `cap_floats` of partial sums.
+uint32_t megakernel_slices(const pt::Params &P, uint32_t c, uint32_t flags, size_t cap_floats) {
+    const uint64_t tiles = (uint64_t)P.tiles_x * ((P.height + 15u) / 16u);
+    const uint64_t pixels = (uint64_t)P.width * P.height;
+    uint64_t slices = std::min<uint64_t>(std::min<uint64_t>(8, c), (65280 + tiles - 1) / tiles);
+    slices = std::min<uint64_t>(slices, cap_floats / (pixels * 3));
+    if ((flags & HIPPT_FLAG_NO_SLICES) || slices < 1) slices = 1;
+    return (uint32_t)slices;
+}
+
 struct PackedScene {
     pt::Params P{};
     std::vector<float4> blob;
@@ -192,6 +203,8 @@ struct hippt_context {
     size_t wf_ws_bytes = 0;
     pt::BvhBuffers bvh;  // LBVH over the spheres (many-sphere scenes only)
     int bvh_depth = 0;
+    std::string bvh_error;  // why the last hippt_set_scene could not build the LBVH (the scene then renders only with HIPPT_FLAG_NO_BVH)
+    int bvh_error_code = HIPPT_OK;
     float *slice_buf = nullptr;  // partial sums of sample slices (launch_megakernel)
     size_t slice_bytes = 0;
     void *chunk_buf = nullptr;  // device staging of the progressive entry points
@@ -259,16 +272,25 @@ int hippt_set_scene(hippt_context *ctx, const hippt_scene *scene) {
         ctx->d_blob_cap = bytes;
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->has_scene = false;  // until the blob and its Params are both in place
     HIP_TRY(hipMemcpy(ctx->d_blob, ps.blob.data(), bytes, hipMemcpyHostToDevice));
     pt::bvh_free(ctx->bvh);
     ctx->bvh_depth = 0;
-    if (scene->n_spheres >= kBvhMinSpheres) {
-        int rc2 = build_bvh(ctx->d_blob, ps.P, ctx->bvh, ctx->stream, &ctx->bvh_depth);
-        if (rc2) return rc2;
-    }
+    ctx->bvh_error.clear();
+    ctx->bvh_error_code = HIPPT_OK;
     ctx->scene = std::move(ps);
     ctx->samples = scene->samples;
     ctx->has_scene = true;
+    if (scene->n_spheres >= kBvhMinSpheres) {
+        // A failed build leaves a consistent scene WITHOUT an LBVH: the call reports the failure, later renders
+        // repeat it unless they ask for the brute-force loops (HIPPT_FLAG_NO_BVH), which need no tree.
+        int rc2 = build_bvh(ctx->d_blob, ctx->scene.P, ctx->bvh, ctx->stream, &ctx->bvh_depth);
+        if (rc2) {
+            ctx->bvh_error = hippt_last_error();
+            ctx->bvh_error_code = rc2;
+            return rc2;
+        }
+    }
     return HIPPT_OK;
 }
 
@@ -289,10 +311,12 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
     bool lds = (size_t)P.blob_f4 * sizeof(float4) <= kMaxLdsBlob;
     if (o.flags & HIPPT_FLAG_TABLES_GLOBAL) lds = false;
     bool use_bvh = ctx->bvh.n > 0 && !(o.flags & HIPPT_FLAG_NO_BVH);
+    if (ctx->bvh_error_code && !(o.flags & HIPPT_FLAG_NO_BVH))
+        return hippt_set_error(ctx->bvh_error_code, "%s (render with HIPPT_FLAG_NO_BVH for the brute-force loops)", ctx->bvh_error.c_str());
     if ((o.flags & HIPPT_FLAG_BVH) && !use_bvh) {
         if (o.flags & HIPPT_FLAG_NO_BVH) return hippt_set_error(HIPPT_ERR_INVALID, "HIPPT_FLAG_BVH and HIPPT_FLAG_NO_BVH are exclusive");
         if (ctx->bvh.n == 0) {  // forced on a scene below the automatic threshold
-            int rc2 = build_bvh(ctx->d_blob, ctx->scene.P, ctx->bvh, ctx->stream, &ctx->bvh_depth);
+            int rc2 = build_bvh(ctx->d_blob, ctx->scene.P, ctx->bvh, st, &ctx->bvh_depth);
             if (rc2) return rc2;
         }
         use_bvh = true;
@@ -341,10 +365,7 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
         else if (use_bvh)
             HIP_TRY(pt::launch_megakernel_bvh(P, ctx->d_blob, bvh_view(ctx->bvh), stack_entries, d_accum, ctx->d_counters, count, st));
         else {
-            // enough blocks for ~50 rounds of the chip's ~1 300 resident blocks (measured: 3 slices +3.4 %, 8 slices +4.6 %, 16 no more)
-            uint64_t tiles = (uint64_t)P.tiles_x * ((P.height + 15u) / 16u);
-            uint32_t slices = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(8, c), (65280 + tiles - 1) / tiles);
-            if (o.flags & HIPPT_FLAG_NO_SLICES) slices = 1;
+            uint32_t slices = megakernel_slices(P, c, o.flags, SIZE_MAX);
             if (slices > 1) {
                 size_t need = (size_t)slices * pixels * 3 * sizeof(float);
                 if (need > ctx->slice_bytes) {
@@ -580,6 +601,25 @@ int hippt_test_occluded(const hippt_scene *scene, uint32_t n, const float *ro, c
     UP(dd, dist2, (size_t)n * 4);
     HIP_TRY(dout.alloc(n));
     if (n) HIP_TRY(pt::launch_unit_occluded(ps.P, blob.as<float4>(), n, dro.as<float>(), drd.as<float>(), dd.as<float>(), dout.as<uint8_t>(), nullptr));
+    DOWN(out, dout, n);
+    return HIPPT_OK;
+}
+
+int hippt_test_shadow_nee(const hippt_scene *scene, uint32_t n, const float *x, const float *l, const float *dist2,
+                          uint8_t *out, int device) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    PackedScene ps;
+    rc = pack_scene(scene, ps);
+    if (rc) return rc;
+    if (ps.blob.size() * 16 > kMaxLdsBlob) return hippt_set_error(HIPPT_ERR_LIMIT, "scene tables exceed the LDS budget of the unit kernel");
+    DevBuf blob, dx, dl, dd, dout;
+    UP(blob, ps.blob.data(), ps.blob.size() * 16);
+    UP(dx, x, (size_t)n * 12);
+    UP(dl, l, (size_t)n * 12);
+    UP(dd, dist2, (size_t)n * 4);
+    HIP_TRY(dout.alloc(n));
+    if (n) HIP_TRY(pt::launch_unit_shadow_nee(ps.P, blob.as<float4>(), n, dx.as<float>(), dl.as<float>(), dd.as<float>(), dout.as<uint8_t>(), nullptr));
     DOWN(out, dout, n);
     return HIPPT_OK;
 }

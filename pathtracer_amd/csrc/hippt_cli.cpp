@@ -75,6 +75,9 @@ int main(int argc, char **argv) {
                 }
                 p = *end == ',' ? end + 1 : end;
             }
+        } else {
+            std::fprintf(stderr, "unknown flag %s\n", a.c_str());
+            return 2;
         }
     }
 
@@ -88,39 +91,11 @@ int main(int argc, char **argv) {
     }
     const hippt_camera &c = sc->camera;
 
-    // src/main.rs:60-87 (camera look_at/up/fov are consumed by the loader; the derived basis is shown instead)
-    std::printf("=== CAMERA INFO ===\n");
-    std::printf(" position : Vec3(%g, %g, %g)\n", c.pos[0], c.pos[1], c.pos[2]);
-    std::printf(" forward  : Vec3(%g, %g, %g)\n", c.forward[0], c.forward[1], c.forward[2]);
-    std::printf(" up       : Vec3(%g, %g, %g)\n", c.up[0], c.up[1], c.up[2]);
-    std::printf(" aspect   : %.4f\n", c.aspect);
-    std::printf(" aperture : %.4f\n", c.aperture);
-    std::printf(" autofocus: %.4f\n", c.focus);
-    uint32_t n_obj = sc->n_spheres + sc->n_planes;
-    std::printf("\n=== OBJECTS (%u) ===\n", n_obj);
-    for (uint32_t o = 0; o < n_obj; ++o) {
-        for (uint32_t i = 0; i < sc->n_spheres; ++i)
-            if (sc->spheres[i].order == o) {
-                const hippt_sphere &s = sc->spheres[i];
-                const float *col = sc->materials[s.material].rgb;
-                std::printf(" [%u] Sphere { center: Vec3(%g, %g, %g), radius: %.4f, mat_color: Vec3(%g, %g, %g) }\n", o,
-                            s.center[0], s.center[1], s.center[2], s.radius, col[0], col[1], col[2]);
-            }
-        for (uint32_t i = 0; i < sc->n_planes; ++i)
-            if (sc->planes[i].order == o) {
-                const hippt_plane &p = sc->planes[i];
-                const float *col = sc->materials[p.material].rgb;
-                std::printf(" [%u] Plane { point: Vec3(%g, %g, %g), normal: Vec3(%g, %g, %g), mat_color: Vec3(%g, %g, %g) }\n",
-                            o, p.point[0], p.point[1], p.point[2], p.normal[0], p.normal[1], p.normal[2], col[0], col[1],
-                            col[2]);
-            }
-    }
-    std::printf("\n=== LIGHTS (%u) ===\n", sc->n_lights);
-    for (uint32_t i = 0; i < sc->n_lights; ++i) {
-        const hippt_light &l = sc->lights[i];
-        std::printf(" [%u] Light { pos: Vec3(%g, %g, %g), u: Vec3(%g, %g, %g), v: Vec3(%g, %g, %g), intensity: Vec3(%g, %g, %g) }\n",
-                    i, l.pos[0], l.pos[1], l.pos[2], l.u[0], l.u[1], l.u[2], l.v[0], l.v[1], l.v[2], l.intensity[0],
-                    l.intensity[1], l.intensity[2]);
+    // src/main.rs:60-87
+    {
+        std::vector<char> dump((size_t)hippt_scene_dump(sf, nullptr, 0) + 1);
+        hippt_scene_dump(sf, dump.data(), dump.size());
+        std::fputs(dump.data(), stdout);
     }
 
     char name[512];

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "hippt_internal.h"
+#include "pt_kernels.h"
 
 namespace {
 
@@ -61,13 +62,20 @@ struct Rank {
     hipStream_t stream = nullptr;
     float *d_accum = nullptr;
     ncclComm_t comm = nullptr;
+    hipEvent_t done = nullptr;  // HIPPT_FLAG_LOCAL_REDUCE: this rank's render has finished
 };
 
-void release(std::vector<Rank> &ranks) {
+void release(std::vector<Rank> &ranks, float *staging = nullptr) {
     const Rccl &R = rccl();
+    if (staging && !ranks.empty()) {
+        (void)hipSetDevice(ranks[0].device);
+        (void)hipFree(staging);
+    }
     for (Rank &k : ranks) {
         (void)hipSetDevice(k.device);
+        if (k.stream) (void)hipStreamSynchronize(k.stream);
         if (k.comm && R.ok) (void)R.CommDestroy(k.comm);
+        if (k.done) (void)hipEventDestroy(k.done);
         if (k.d_accum) (void)hipFree(k.d_accum);
         if (k.stream) (void)hipStreamDestroy(k.stream);
         if (k.ctx) hippt_destroy(k.ctx);
@@ -75,21 +83,51 @@ void release(std::vector<Rank> &ranks) {
     ranks.clear();
 }
 
-// Renders the sample range of `opts` (whole image if its count is 0) split over the devices and leaves the reduced
-// sums in ranks[0].d_accum; the caller resolves or copies them and then calls release().
+// Sum of the ranks' accumulators on ranks[0] without RCCL (HIPPT_FLAG_LOCAL_REDUCE): rank 0's stream waits for each
+// rank's render, fetches the rank's sums (in place if the rank shares rank 0's device, by peer copy into a staging
+// buffer otherwise) and adds them with a small kernel, ranks in ascending order (deterministic).
+int local_reduce(std::vector<Rank> &ranks, size_t n_float, float **staging) {
+    Rank &r0 = ranks[0];
+    for (size_t i = 1; i < ranks.size(); ++i) {
+        Rank &k = ranks[i];
+        hipError_t e = hipSetDevice(k.device);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&k.done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(k.done, k.stream);
+        if (e == hipSuccess) e = hipSetDevice(r0.device);
+        if (e == hipSuccess) e = hipStreamWaitEvent(r0.stream, k.done, 0);
+        const float *src = k.d_accum;
+        if (e == hipSuccess && k.device != r0.device) {
+            if (!*staging) e = hipMalloc((void **)staging, n_float * sizeof(float));
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(*staging, r0.device, k.d_accum, k.device, n_float * sizeof(float), r0.stream);
+            src = *staging;
+        }
+        if (e == hipSuccess) e = pt::launch_add(r0.d_accum, src, n_float, r0.stream);
+        if (e != hipSuccess) return hippt_set_error(HIPPT_ERR_DEVICE, "local reduce of device %d: %s", k.device, hipGetErrorString(e));
+    }
+    return HIPPT_OK;
+}
+
+// Renders the sample range of `opts` (from sample_begin to the image's last sample if its count is 0, as the
+// one-device entry points read it) split over the devices and leaves the reduced sums in ranks[0].d_accum; the caller
+// resolves or copies them and then calls release().
 int render_reduced(const hippt_scene *scene, const hippt_options *opts, const int *devices, int n_devices,
-                   std::vector<Rank> &ranks, uint32_t *spp_out) {
+                   std::vector<Rank> &ranks, uint32_t *spp_out, float **staging) {
     if (!scene || !devices || n_devices < 1) return hippt_set_error(HIPPT_ERR_INVALID, "bad multi-GPU arguments");
-    for (int i = 0; i < n_devices; ++i)
-        for (int j = 0; j < i; ++j)
-            if (devices[i] == devices[j]) return hippt_set_error(HIPPT_ERR_INVALID, "device %d is listed twice", devices[i]);
-    const Rccl &R = rccl();
-    if (!R.ok)
-        return hippt_set_error(HIPPT_ERR_DEVICE, "librccl.so could not be opened (set HIPPT_RCCL_LIB): %s", dlerror() ? dlerror() : "symbols missing");
     hippt_options base{};
     if (opts) base = *opts;
-    const uint32_t s0 = base.sample_count ? base.sample_begin : 0u;
-    const uint32_t total = base.sample_count ? base.sample_count : scene->samples;
+    const bool local = (base.flags & HIPPT_FLAG_LOCAL_REDUCE) != 0;
+    base.flags &= ~HIPPT_FLAG_LOCAL_REDUCE;
+    if (!local)  // RCCL wants one rank per device; the local reduce lets a one-GPU box rehearse several ranks
+        for (int i = 0; i < n_devices; ++i)
+            for (int j = 0; j < i; ++j)
+                if (devices[i] == devices[j]) return hippt_set_error(HIPPT_ERR_INVALID, "device %d is listed twice", devices[i]);
+    const Rccl &R = rccl();
+    if (!local && !R.ok) {
+        const char *why = dlerror();
+        return hippt_set_error(HIPPT_ERR_DEVICE, "librccl.so could not be opened (set HIPPT_RCCL_LIB): %s", why ? why : "symbols missing");
+    }
+    const uint32_t s0 = base.sample_begin;
+    const uint32_t total = base.sample_count ? base.sample_count : (scene->samples > s0 ? scene->samples - s0 : 0u);
     if (spp_out) *spp_out = total;
     const size_t n_float = (size_t)scene->width * scene->height * 3;
 
@@ -107,6 +145,14 @@ int render_reduced(const hippt_scene *scene, const hippt_options *opts, const in
             return hippt_set_error(HIPPT_ERR_DEVICE, "device %d: stream or accumulator allocation failed (%zu bytes)", k.device,
                                    n_float * sizeof(float));
     }
+    // One communicator per device, BEFORE any render is queued: communicator setup allocates and synchronises on
+    // every device, and a failure here must not cost a full render.
+    if (!local) {
+        std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
+        ncclResult_t nr = R.CommInitAll(comms.data(), n_devices, devices);
+        for (int i = 0; i < n_devices; ++i) ranks[(size_t)i].comm = comms[(size_t)i];
+        if (nr != ncclSuccess) return hippt_set_error(HIPPT_ERR_DEVICE, "ncclCommInitAll over %d devices: %s", n_devices, R.GetErrorString(nr));
+    }
     // one host thread per device: the queue pipelines (LBVH scenes) poll their counters and block their caller
     std::vector<int> codes((size_t)n_devices, HIPPT_OK);
     std::vector<std::string> messages((size_t)n_devices);
@@ -123,23 +169,23 @@ int render_reduced(const hippt_scene *scene, const hippt_options *opts, const in
             if (codes[(size_t)i]) messages[(size_t)i] = hippt_last_error();  // the message is per thread
         });
     }
-    // meanwhile: one communicator per device
-    std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
-    ncclResult_t nr = R.CommInitAll(comms.data(), n_devices, devices);
-    for (int i = 0; i < n_devices; ++i) ranks[(size_t)i].comm = comms[(size_t)i];
     for (std::thread &t : workers) t.join();
     for (int i = 0; i < n_devices; ++i)
         if (codes[(size_t)i]) return hippt_set_error(codes[(size_t)i], "device %d: %s", devices[i], messages[(size_t)i].c_str());
-    if (nr != ncclSuccess) return hippt_set_error(HIPPT_ERR_DEVICE, "ncclCommInitAll over %d devices: %s", n_devices, R.GetErrorString(nr));
-    // one grouped reduce onto rank 0 (in place there), each rank's part on its device's stream, behind its render
-    nr = R.GroupStart();
-    for (int i = 0; i < n_devices && nr == ncclSuccess; ++i) {
-        Rank &k = ranks[(size_t)i];
-        nr = R.Reduce(k.d_accum, k.d_accum, n_float, ncclFloat32, ncclSum, 0, k.comm, k.stream);
+    if (local) {
+        int rc = local_reduce(ranks, n_float, staging);
+        if (rc) return rc;
+    } else {
+        // one grouped reduce onto rank 0 (in place there), each rank's part on its device's stream, behind its render
+        ncclResult_t nr = R.GroupStart();
+        for (int i = 0; i < n_devices && nr == ncclSuccess; ++i) {
+            Rank &k = ranks[(size_t)i];
+            nr = R.Reduce(k.d_accum, k.d_accum, n_float, ncclFloat32, ncclSum, 0, k.comm, k.stream);
+        }
+        ncclResult_t ne = R.GroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        if (nr != ncclSuccess) return hippt_set_error(HIPPT_ERR_DEVICE, "ncclReduce: %s", R.GetErrorString(nr));
     }
-    ncclResult_t ne = R.GroupEnd();
-    if (nr == ncclSuccess) nr = ne;
-    if (nr != ncclSuccess) return hippt_set_error(HIPPT_ERR_DEVICE, "ncclReduce: %s", R.GetErrorString(nr));
     for (Rank &k : ranks) {
         hipError_t e = hipSetDevice(k.device);
         if (e == hipSuccess) e = hipStreamSynchronize(k.stream);
@@ -171,14 +217,15 @@ int hippt_render_accum_f32_multi(const hippt_scene *scene, const hippt_options *
                                  float *out_accum) {
     if (!out_accum) return hippt_set_error(HIPPT_ERR_INVALID, "out_accum is NULL");
     std::vector<Rank> ranks;
-    int rc = render_reduced(scene, opts, devices, n_devices, ranks, nullptr);
+    float *staging = nullptr;
+    int rc = render_reduced(scene, opts, devices, n_devices, ranks, nullptr, &staging);
     if (rc == HIPPT_OK) {
         hipError_t e = hipSetDevice(ranks[0].device);
         if (e == hipSuccess)
             e = hipMemcpy(out_accum, ranks[0].d_accum, (size_t)scene->width * scene->height * 3 * sizeof(float), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = hippt_set_error(HIPPT_ERR_DEVICE, "copy out: %s", hipGetErrorString(e));
     }
-    release(ranks);
+    release(ranks, staging);
     return rc;
 }
 
@@ -192,7 +239,8 @@ int hippt_render_rgba8_multi(const hippt_scene *scene, const hippt_options *opts
     whole.sample_count = 0;  // the image's own sample count
     std::vector<Rank> ranks;
     uint32_t spp = 0;
-    int rc = render_reduced(scene, &whole, devices, n_devices, ranks, &spp);
+    float *staging = nullptr;
+    int rc = render_reduced(scene, &whole, devices, n_devices, ranks, &spp, &staging);
     uint8_t *d_rgba = nullptr;
     if (rc == HIPPT_OK) {
         const size_t npx = (size_t)scene->width * scene->height;
@@ -207,7 +255,7 @@ int hippt_render_rgba8_multi(const hippt_scene *scene, const hippt_options *opts
         }
     }
     if (d_rgba) (void)hipFree(d_rgba);
-    release(ranks);
+    release(ranks, staging);
     return rc;
 }
 

@@ -8,6 +8,7 @@
 // autofocus distance round exactly as the reference's f32 arithmetic does.
 #include <zlib.h>
 
+#include <algorithm>
 #include <cctype>
 #include <cerrno>
 #include <cmath>
@@ -309,7 +310,8 @@ struct hippt_scene_file {
     std::vector<hippt_sphere> spheres;
     std::vector<hippt_plane> planes;
     std::vector<hippt_light> lights;
-    // raw camera inputs, kept so that a render-size override can re-derive the basis
+    std::vector<std::string> names;  // object names in scene order (sphere.rs:10, plane.rs:9; shown by main.rs:73,77)
+    // raw camera inputs, kept so that a render-size override can re-derive the basis (and for main.rs:61-64's dump)
     float cam_pos[3], cam_look_at[3], cam_up[3], cam_fov, cam_aperture;
     void rebind() {
         scene.n_materials = (uint32_t)materials.size();
@@ -484,6 +486,7 @@ int hippt_scene_parse(const char *json_text, size_t len, hippt_scene_file **out)
                 s.order = order;
                 s.in_focus = in_focus ? 1u : 0u;
                 f->spheres.push_back(s);
+                f->names.push_back(name);
                 done = true;
             } else if (!pv) {
                 ex.err = es.err;
@@ -502,6 +505,7 @@ int hippt_scene_parse(const char *json_text, size_t len, hippt_scene_file **out)
             p.order = order;
             p.in_focus = in_focus ? 1u : 0u;
             f->planes.push_back(p);
+            f->names.push_back(name);
             done = true;
         }
         if (!done) {
@@ -556,6 +560,104 @@ int hippt_scene_set_render(hippt_scene_file *f, uint32_t width, uint32_t height,
 }
 
 void hippt_scene_free(hippt_scene_file *f) { delete f; }
+
+}  // extern "C"
+
+// ---- src/main.rs:60-87: the debug dump ------------------------------------------------
+namespace {
+// Rust's `{:?}` of an f32 (core::fmt::float::float_to_general_debug): the shortest digits that read back as the
+// same f32; decimal notation with at least one fractional digit ("1.0") for 1e-4 <= |x| < 1e16 and for zero,
+// otherwise `d.ddde-7` style exponent notation.
+std::string rust_debug_f32(float x) {
+    if (std::isnan(x)) return "NaN";
+    if (std::isinf(x)) return x < 0 ? "-inf" : "inf";
+    char buf[64];
+    int prec = 0;
+    for (; prec < 9; ++prec) {
+        std::snprintf(buf, sizeof buf, "%.*e", prec, (double)x);
+        if (std::strtof(buf, nullptr) == x) break;
+    }
+    // buf = [-]d[.ddd]e[+-]XX
+    std::string t = buf;
+    const bool neg = t[0] == '-';
+    if (neg) t.erase(0, 1);
+    const size_t epos = t.find('e');
+    int e10 = std::atoi(t.c_str() + epos + 1);
+    std::string digits;
+    for (char c : t.substr(0, epos))
+        if (c != '.') digits.push_back(c);
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+    const float ax = std::fabs(x);
+    std::string out = neg ? "-" : "";
+    if (ax != 0.0f && (ax >= 1e16f || ax < 1e-4f)) {
+        out += digits.substr(0, 1);
+        if (digits.size() > 1) out += "." + digits.substr(1);
+        out += "e" + std::to_string(e10);
+        return out;
+    }
+    if (ax == 0.0f) return out + "0.0";
+    if (e10 >= 0) {
+        std::string ip = digits.substr(0, std::min(digits.size(), (size_t)e10 + 1));
+        ip.append((size_t)e10 + 1 - ip.size(), '0');
+        std::string fp = digits.size() > (size_t)e10 + 1 ? digits.substr((size_t)e10 + 1) : "0";
+        return out + ip + "." + fp;
+    }
+    return out + "0." + std::string((size_t)(-e10 - 1), '0') + digits;
+}
+std::string rust_debug_vec3(const float v[3]) {
+    return "Vec3(" + rust_debug_f32(v[0]) + ", " + rust_debug_f32(v[1]) + ", " + rust_debug_f32(v[2]) + ")";
+}
+std::string fixed(float x, int prec) {
+    char b[64];
+    std::snprintf(b, sizeof b, "%.*f", prec, (double)x);
+    return b;
+}
+}  // namespace
+
+extern "C" {
+
+int hippt_scene_dump(const hippt_scene_file *f, char *out, size_t cap) {
+    if (!f) return -1;
+    const hippt_scene &sc = f->scene;
+    std::string s;
+    s += "=== CAMERA INFO ===\n";
+    s += " position : " + rust_debug_vec3(f->cam_pos) + "\n";
+    s += " look_at  : " + rust_debug_vec3(f->cam_look_at) + "\n";
+    s += " up       : " + rust_debug_vec3(f->cam_up) + "\n";
+    s += " fov (\xC2\xB0)  : " + fixed(f->cam_fov, 2) + "\n";
+    s += " aspect   : " + fixed(sc.camera.aspect, 4) + "\n";
+    s += " aperture : " + fixed(f->cam_aperture, 4) + "\n";
+    s += " autofocus: " + fixed(sc.camera.focus, 4) + "\n";
+    const uint32_t n_obj = sc.n_spheres + sc.n_planes;
+    s += "\n=== OBJECTS (" + std::to_string(n_obj) + ") ===\n";
+    for (uint32_t o = 0; o < n_obj; ++o) {
+        const std::string name = o < f->names.size() ? f->names[o] : std::string();
+        for (uint32_t i = 0; i < sc.n_spheres; ++i)
+            if (sc.spheres[i].order == o) {
+                const hippt_sphere &sp = sc.spheres[i];
+                s += " [" + std::to_string(o) + "] Sphere '" + name + "' { center: " + rust_debug_vec3(sp.center) +
+                     ", radius: " + fixed(sp.radius, 4) + ", mat_color: " + rust_debug_vec3(sc.materials[sp.material].rgb) + " }\n";
+            }
+        for (uint32_t i = 0; i < sc.n_planes; ++i)
+            if (sc.planes[i].order == o) {
+                const hippt_plane &pl = sc.planes[i];
+                s += " [" + std::to_string(o) + "] Plane '" + name + "' { point: " + rust_debug_vec3(pl.point) +
+                     ", normal: " + rust_debug_vec3(pl.normal) + ", mat_color: " + rust_debug_vec3(sc.materials[pl.material].rgb) + " }\n";
+            }
+    }
+    s += "\n=== LIGHTS (" + std::to_string(sc.n_lights) + ") ===\n";
+    for (uint32_t i = 0; i < sc.n_lights; ++i) {
+        const hippt_light &l = sc.lights[i];
+        s += " [" + std::to_string(i) + "] Light { pos: " + rust_debug_vec3(l.pos) + ", u: " + rust_debug_vec3(l.u) +
+             ", v: " + rust_debug_vec3(l.v) + ", intensity: " + rust_debug_vec3(l.intensity) + " }\n";
+    }
+    if (out && cap) {
+        const size_t n = std::min(cap - 1, s.size());
+        std::memcpy(out, s.data(), n);
+        out[n] = 0;
+    }
+    return (int)s.size();
+}
 
 // src/renderer.rs:156-161
 int hippt_render_image_name(uint32_t w, uint32_t h, uint32_t s, float ap, float f, char *out, size_t cap) {

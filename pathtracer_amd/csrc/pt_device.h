@@ -450,9 +450,20 @@ __device__ __forceinline__ F3 fresnel_schlick(float cos_theta, F3 f0) {
     return F3{fmaf(1.0f - f0.x, w, f0.x), fmaf(1.0f - f0.y, w, f0.y), fmaf(1.0f - f0.z, w, f0.z)};
 }
 // ggx.rs:10-12 (a = roughness, un-squared: quirk Q7)
+// q = nh^2 (a^2 - 1) + 1 with the reference's roundings (product rounded, then the sum): at roughness 0.01 and
+// nh -> 1 it is a cancellation down to a^2 = 1e-4, so a fused product moves D by up to 1e-3 relative.
+// (a^2 - 1 likewise: fused into fma(a, a, -1) it differs from the reference's by half an ulp of a^2, which q amplifies.)
+__device__ __forceinline__ float ggx_a2m1(float a2) {
+#pragma clang fp contract(off)
+    return a2 - 1.0f;
+}
+__device__ __forceinline__ float ggx_q(float nh, float a2m1) {
+#pragma clang fp contract(off)
+    return (nh * nh) * a2m1 + 1.0f;
+}
 __device__ __forceinline__ float d_term(float nh, float a) {
     float a2 = a * a;
-    float q = fmaf(nh * nh, a2 - 1.0f, 1.0f);
+    float q = ggx_q(nh, ggx_a2m1(a2));
     return a2 * rcp(3.14159265358979323846f * (q * q));
 }
 // ggx.rs:13-18
@@ -563,7 +574,7 @@ __device__ __forceinline__ ShadeK make_shade(F3 n, F3 v, const Mat &m) {
     s.diffuse_over_pi = m.color * (om * 0.31830988618379067154f);
     float nv = fmaxf(dot(n, v), 1e-4f);
     float a2 = m.roughness * m.roughness;
-    s.a2m1 = a2 - 1.0f;
+    s.a2m1 = ggx_a2m1(a2);
     s.k = 0.5f * a2;
     s.four_nv = 4.0f * nv;
     s.spec_v = a2 * nv * rcp(3.14159265358979323846f * fmaf(nv, 1.0f - s.k, s.k));
@@ -588,7 +599,7 @@ __device__ __forceinline__ F3 nee_eval(const ShadeK &s, F3 l, float inv_dist2, F
     float n_dot_h = fmaxf(dot(s.n, h), 0.0f);
     float v_dot_h = fmaxf(dot(s.v, h), 0.0f);
     F3 f = fresnel_schlick(v_dot_h, s.f0);
-    float q = fmaf(n_dot_h * n_dot_h, s.a2m1, 1.0f);
+    float q = ggx_q(n_dot_h, s.a2m1);
     float den = (q * q) * fmaf(n_dot_l, 1.0f - s.k, s.k) * fmaf(s.four_nv, n_dot_l, 1e-6f);
     float spec = (s.spec_v * n_dot_l) * rcp(den);
     F3 kd = F3{1.0f - f.x, 1.0f - f.y, 1.0f - f.z};

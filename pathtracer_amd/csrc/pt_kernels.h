@@ -26,12 +26,16 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
                                 void *workspace, hipStream_t st, uint32_t *iterations_out);
 hipError_t wavefront_render(const Params &P, const float4 *blob, float *accum, void *workspace, hipStream_t st,
                             uint32_t *iterations_out);
+// dst[i] += src[i] (sum of per-rank accumulators on one device)
+hipError_t launch_add(float *dst, const float *src, size_t n, hipStream_t st);
 hipError_t launch_resolve(const float *accum, uint32_t n_pixels, uint32_t spp, uint8_t *rgba, hipStream_t st);
 
 hipError_t launch_unit_intersect(const Params &P, const float4 *blob, uint32_t n, const float *ro, const float *rd,
                                  float *t, float *nn, int32_t *idx, hipStream_t st);
 hipError_t launch_unit_occluded(const Params &P, const float4 *blob, uint32_t n, const float *ro, const float *rd,
                                 const float *dist2, uint8_t *out, hipStream_t st);
+hipError_t launch_unit_shadow_nee(const Params &P, const float4 *blob, uint32_t n, const float *x, const float *l,
+                                  const float *dist2, uint8_t *out, hipStream_t st);
 hipError_t launch_unit_nee_eval(uint32_t n, const float *nrm, const float *v, const float *l, const float *dist2,
                                 const float *mat, const hippt_light &light, float *out, hipStream_t st);
 hipError_t launch_unit_ggx_terms(uint32_t n, const float *nh, const float *nv, const float *nl, const float *vh,

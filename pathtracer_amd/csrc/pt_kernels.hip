@@ -26,12 +26,17 @@ __device__ __forceinline__ void lane_pixel(const Params &P, uint32_t &x, uint32_
 #ifndef PT_SHARED_NEE
 #define PT_SHARED_NEE 1
 #endif
-// Per-wave scratch in LDS: the 64 pixels' radiance sums and their RNG pixel keys.
-struct WaveLds {
+// Per-wave scratch in LDS: the 64 pixels' radiance sums and their RNG pixel keys ...
+struct WaveAcc {
     float acc[64 * 3];
     uint32_t mix[64];
+};
+// ... and, for the kernels that run the wave-shared lights loop, its state (the LBVH megakernel does not: its LDS
+// goes to the traversal stacks, up to BVH_STACK x 1 KiB per block)
+struct WaveLds : WaveAcc {
     NeeShare nee;  // Tracer::direct_light_shared
 };
+static_assert(4 * sizeof(WaveAcc) + (size_t)BVH_STACK * 256 * 4 <= 64 * 1024, "LBVH megakernel: stacks + pixel sums exceed a block's 64 KiB of LDS");
 
 // One wave renders the sample_count samples of its 8x8 pixels as a POOL of 64 * sample_count work items
 // (item i = sample i / 64 of pixel i % 64): a lane whose path has ended takes the next item, whichever
@@ -40,10 +45,11 @@ struct WaveLds {
 // only, and a finished path's radiance is added to its pixel's sum in LDS, so the image is the same as
 // with one lane per pixel up to the order of the f32 additions (which is fixed: the item order and the LDS
 // atomics of a wave are deterministic).
-template <class Tbl, bool COUNT, bool BVH = false>
+template <class Tbl, bool COUNT, bool BVH = false, class WL = WaveLds>
 __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x_own, uint32_t y_own, bool in_image,
                                             float *__restrict__ accum, unsigned long long *__restrict__ counters,
-                                            WaveLds *wl, Bvh bvh = Bvh{}, uint32_t *stack = nullptr, bool overwrite = false) {
+                                            WL *wl, Bvh bvh = Bvh{}, uint32_t *stack = nullptr, bool overwrite = false) {
+    constexpr bool kSharedNee = PT_SHARED_NEE && !COUNT && !BVH;
     Tracer<Tbl, COUNT, BVH> tr(P, tbl, bvh, stack);
 #ifdef PT_NEE_DIAG
     tr.diag = counters;
@@ -56,8 +62,10 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
     wl->acc[lane * 3 + 0] = 0.0f;
     wl->acc[lane * 3 + 1] = 0.0f;
     wl->acc[lane * 3 + 2] = 0.0f;
-    if (lane < kHintLights) wl->nee.hint[lane] = kNoHint;
-    if (lane == 0u) wl->nee.pending = 0u;
+    if constexpr (kSharedNee) {
+        if (lane < kHintLights) wl->nee.hint[lane] = kNoHint;
+        if (lane == 0u) wl->nee.pending = 0u;
+    }
     __builtin_amdgcn_wave_barrier();
 
     uint32_t cur_lane = 0, cur_sample = 0;  // wave-uniform cursor into the item sequence
@@ -151,7 +159,6 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
             }
         }
 
-        constexpr bool kSharedNee = PT_SHARED_NEE && !COUNT && !BVH;
         F3 D;
         if constexpr (kSharedNee) tr.direct_light_shared(kind != 0, x, n, -rd, m, rng, T, psum, my_pl, &wl->nee, wl->acc);
         if (kind != 0) {
@@ -205,7 +212,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
         }
     }
 
-    if constexpr (PT_SHARED_NEE && !COUNT && !BVH) tr.flush_pairs(&wl->nee, wl->acc);
+    if constexpr (kSharedNee) tr.flush_pairs(&wl->nee, wl->acc);
     __builtin_amdgcn_wave_barrier();
     if (in_image) {
         float *px = accum + (size_t)pixel * 3;
@@ -283,9 +290,9 @@ __global__ __launch_bounds__(256) void pt_megakernel_bvh(Params P, const float4 
     uint32_t x, y;
     lane_pixel(P, x, y);
     bool in_image = (x < P.width) & (y < P.height);
-    __shared__ WaveLds s_wl[4];
-    trace_pixel<TblGlobal, COUNT, true>(P, TblGlobal{blob}, x, y, in_image, accum, counters, &s_wl[threadIdx.x >> 6], bvh,
-                                        s_stack + threadIdx.x);
+    __shared__ WaveAcc s_wl[4];
+    trace_pixel<TblGlobal, COUNT, true, WaveAcc>(P, TblGlobal{blob}, x, y, in_image, accum, counters, &s_wl[threadIdx.x >> 6], bvh,
+                                                 s_stack + threadIdx.x);
 }
 
 // renderer.rs:184-191
@@ -372,6 +379,30 @@ __global__ void pt_unit_occluded(Params P, const float4 *__restrict__ blob, uint
     uint32_t a = 0, b = 0;
     occluded_multi<TblLds, 1, false>(tbl, P, ld3(ro, i), 0.0f, l, lim, occ, a, b);
     out[i] = occ[0] ? 1 : 0;
+}
+
+// The shadow test AS NEXT-EVENT ESTIMATION USES IT (renderer.rs:44-46): 4 rays per lane from the shading point x,
+// the origin offset eps = 1e-4 folded into the arithmetic (pt_device.h: sphere_shadow_row / plane_shadow_row), tmax
+// formed from dist2 exactly as Tracer::direct_light forms it. The lane's ray sits in all 4 slots; bit 1 of the output
+// is set if the slots disagree.
+__global__ void pt_unit_shadow_nee(Params P, const float4 *__restrict__ blob, uint32_t n, const float *x,
+                                   const float *l, const float *dist2, uint8_t *out) {
+    extern __shared__ float4 s_tbl[];
+    for (uint32_t i = threadIdx.x; i < P.blob_f4; i += blockDim.x) s_tbl[i] = blob[i];
+    __syncthreads();
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    TblLds tbl{s_tbl};
+    const F3 li = ld3(l, i);
+    const float d2 = dist2[i];
+    const float tm = (d2 * rsq(d2)) * 0.99949987493746f;  // |lvec| sqrt(0.999)
+    F3 ls[4] = {li, li, li, li};
+    float lim[4] = {tm, tm, tm, tm};
+    bool occ[4];
+    uint32_t a = 0, b = 0;
+    occluded_multi<TblLds, 4, false>(tbl, P, ld3(x, i), 1e-4f, ls, lim, occ, a, b);
+    const bool same = (occ[0] == occ[1]) & (occ[1] == occ[2]) & (occ[2] == occ[3]);
+    out[i] = (occ[0] ? 1 : 0) | (same ? 0 : 2);
 }
 
 __global__ void pt_unit_nee_eval(uint32_t n, const float *nrm, const float *v, const float *l, const float *dist2,
@@ -508,10 +539,16 @@ hipError_t launch_megakernel_bvh(const Params &P, const float4 *blob, const Bvh 
                                  unsigned long long *counters, bool count, hipStream_t st) {
     uint32_t tiles_y = (P.height + 15u) / 16u;
     dim3 grid(P.tiles_x * tiles_y), block(256);
+    if (4 * sizeof(WaveAcc) + (size_t)stack_entries * 256 * 4 > 64 * 1024) return hipErrorInvalidValue;  // a block's LDS without opt-in
     if (count)
         hipLaunchKernelGGL(pt_megakernel_bvh<true>, grid, block, (size_t)stack_entries * 256 * 4, st, P, blob, bvh, accum, counters);
     else
         hipLaunchKernelGGL(pt_megakernel_bvh<false>, grid, block, (size_t)stack_entries * 256 * 4, st, P, blob, bvh, accum, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_add(float *dst, const float *src, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(pt_add_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, src, 1u, n);
     return hipGetLastError();
 }
 
@@ -541,6 +578,11 @@ hipError_t launch_unit_occluded(const Params &P, const float4 *blob, uint32_t n,
                                 const float *dist2, uint8_t *out, hipStream_t st) {
     hipLaunchKernelGGL(pt_unit_occluded, dim3(grid_for(n)), dim3(256), (size_t)P.blob_f4 * 16, st, P, blob, n, ro, rd,
                        dist2, out);
+    return hipGetLastError();
+}
+hipError_t launch_unit_shadow_nee(const Params &P, const float4 *blob, uint32_t n, const float *x, const float *l,
+                                  const float *dist2, uint8_t *out, hipStream_t st) {
+    hipLaunchKernelGGL(pt_unit_shadow_nee, dim3(grid_for(n)), dim3(256), (size_t)P.blob_f4 * 16, st, P, blob, n, x, l, dist2, out);
     return hipGetLastError();
 }
 hipError_t launch_unit_nee_eval(uint32_t n, const float *nrm, const float *v, const float *l, const float *dist2,

@@ -171,3 +171,21 @@ class Scene:
         sc.planes = keep[2].ctypes.data_as(C.POINTER(_abi.Plane))
         sc.lights = keep[3].ctypes.data_as(C.POINTER(_abi.Light))
         return sc, keep
+
+
+def dump(path, width=None, height=None, samples=None):
+    """The text main() prints before rendering (src/main.rs:60-87) for the scene file at `path`."""
+    lib = _abi.load_library()
+    h = C.c_void_p()
+    _abi.check(lib.hippt_scene_load(str(path).encode(), C.byref(h)), lib)
+    try:
+        if width or height or samples:
+            sc = lib.hippt_scene_get(h).contents
+            _abi.check(lib.hippt_scene_set_render(h, width or sc.width, height or sc.height,
+                                                  samples if samples is not None else sc.samples), lib)
+        n = lib.hippt_scene_dump(h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib.hippt_scene_dump(h, buf, n + 1)
+        return buf.value.decode()
+    finally:
+        lib.hippt_scene_free(h)

@@ -66,6 +66,15 @@ class UnitOps:
         self._call("occluded", C.byref(sc), C.c_uint32(n), _p(ro), _p(rd), _p(dist2), _p(out), C.c_int(self.device))
         return out
 
+    def shadow_nee(self, scene, x, l, dist2):
+        """renderer.rs:44-46 as NEE runs it: shading point x, unit direction l, dist2 -> bit 0 occluded, bit 1 slot mismatch."""
+        x, l, dist2 = _f32(x, (-1, 3)), _f32(l, (-1, 3)), _f32(dist2)
+        n = len(x)
+        out = np.empty(n, np.uint8)
+        sc, _keep = scene.to_c()
+        self._call("shadow_nee", C.byref(sc), C.c_uint32(n), _p(x), _p(l), _p(dist2), _p(out), C.c_int(self.device))
+        return out
+
     def nee_eval(self, nrm, v, l, dist2, mat, light):
         nrm, v, l, dist2, mat = _f32(nrm, (-1, 3)), _f32(v, (-1, 3)), _f32(l, (-1, 3)), _f32(dist2), _f32(mat, (-1, 8))
         n = len(nrm)

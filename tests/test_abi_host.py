@@ -206,3 +206,58 @@ def test_sample_range_matches_partition():
             assert got == [sample_range(total, r, world) for r in range(world)]
             assert sum(c for _, c in got) == total and got[0][0] == 0
             assert all(got[r][0] + got[r][1] == got[r + 1][0] for r in range(world - 1))
+
+
+def test_debug_dump_is_main_rs_60_87():
+    """hippt_scene_dump == the text of src/main.rs:60-87 for scene.example.json: position / look_at / up / fov lines,
+    object names, and floats as Rust's `{:?}` prints them (shortest round-trip digits, "1.0", "-0.0", "1.509958e-7").
+    The expected block is written out literally; the f32 digits are cross-checked against numpy's shortest repr."""
+    from pathtracer_amd import scene
+    expected = """=== CAMERA INFO ===
+ position : Vec3(0.0, 0.4057229, -1.1699998)
+ look_at  : Vec3(1.509958e-7, 0.40572315, -0.16999984)
+ up       : Vec3(-2.719304e-14, 1.0, -2.8212997e-7)
+ fov (°)  : 60.00
+ aspect   : 1.3333
+ aperture : 0.0200
+ autofocus: 5.0000
+
+=== OBJECTS (7) ===
+ [0] Plane 'Plane' { point: Vec3(0.0, -0.81, 8.54), normal: Vec3(-3.727507e-6, -1.0, 3.7591824e-6), mat_color: Vec3(0.27521268, 0.68945605, 0.80049694) }
+ [1] Sphere 'Sphere' { center: Vec3(1.1354003, -0.3700193, 4.418177), radius: 1.0000, mat_color: Vec3(0.8, 0.8, 0.8) }
+ [2] Sphere 'Sphere.001' { center: Vec3(-1.1011227, -0.5954898, 4.7919927), radius: 1.0000, mat_color: Vec3(0.50519305, 0.7576715, 0.80034703) }
+ [3] Sphere 'Sphere.002' { center: Vec3(0.013796618, -0.7068826, 2.941975), radius: 0.5200, mat_color: Vec3(0.8, 0.8, 0.8) }
+ [4] Plane 'Plane.001' { point: Vec3(-2.5, 0.0, 0.0), normal: Vec3(1.0, -4.5144347e-8, 0.0), mat_color: Vec3(0.7061524, 0.33920133, 0.8003553) }
+ [5] Plane 'Plane.002' { point: Vec3(2.5, 0.0, 0.0), normal: Vec3(-1.0, -4.5144347e-8, -0.0), mat_color: Vec3(0.7061524, 0.33920133, 0.8003553) }
+ [6] Plane 'Plane.003' { point: Vec3(0.0, 0.0, 7.2), normal: Vec3(0.0, 0.7986356, -0.601815), mat_color: Vec3(0.8, 0.8, 0.8) }
+
+=== LIGHTS (2) ===
+ [0] Light { pos: Vec3(0.0, 2.95, 4.0), u: Vec3(-1.0, -0.0, -0.0), v: Vec3(0.0, 2.3841858e-7, -1.0), intensity: Vec3(25.0, 25.0, 25.0) }
+ [1] Light { pos: Vec3(0.0, 0.32999998, 11.379999), u: Vec3(-1.0, -0.0, -0.0), v: Vec3(0.0, 0.9993908, 0.03489971), intensity: Vec3(50.0, 50.0, 50.0) }
+"""
+    got = scene.dump(os.path.join(ROOT, "scenes", "scene.example.json"))
+    assert got == expected
+    # independent witness for the digit strings: numpy prints the shortest round-trip form of an f32 too
+    import json
+    cam = json.load(open(os.path.join(ROOT, "scenes", "scene.example.json")))["camera"]
+    for v in cam["pos"] + cam["look_at"] + cam["up"]:
+        f = np.float32(v)
+        s = np.format_float_scientific(f, unique=True, trim="-", exp_digits=1).replace("e+", "e") if (f != 0 and (abs(f) < 1e-4 or abs(f) >= 1e16)) \
+            else np.format_float_positional(f, unique=True, trim="0")
+        assert s in got, s
+    # render overrides change aspect only
+    assert " aspect   : 1.7778\n" in scene.dump(os.path.join(ROOT, "scenes", "scene.example.json"), 1920, 1080, 4)
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """libhippt loaded BEFORE torch used to leave two HIP runtimes in the process (the system ROCm's for libhippt,
+    the wheel's own for torch): a torch stream passed to the C ABI then belonged to the other runtime. _abi loads the
+    wheel's copy first when torch is installed."""
+    import subprocess
+    import sys
+    code = ("from pathtracer_amd import _abi; _abi.load_library(); import torch; "
+            "m = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}; print(len(m)); print(sorted(m))")
+    for order in (code, "import torch; " + code):
+        r = subprocess.run([sys.executable, "-c", order], cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.split()[0] == "1", r.stdout

@@ -110,7 +110,15 @@ def test_nee_eval(hip, oracle):
     nl = np.einsum("ij,ij->i", n.astype(np.float64), l)      # n.l scales the whole result (grazing light)
     assert err[(q > 0.5) & (hlen > 0.5) & (nv > 0.05) & (nl > 0.05)].max() < TOL
     assert err[(q > 0.1) & (hlen > 0.2) & (nv > 0.01) & (nl > 0.01)].max() < 1e-4
-    assert err.max() < 2e-2
+    # MAX bound over every sample, not only quantiles: q itself is formed with the reference's roundings
+    # (pt_device.h: ggx_q), so what is left is the last bit of n.h (h comes from v_rsq_f32 and fused dot products
+    # here, from sqrt / divide / unfused products in the reference), amplified by 1/q in D (1/q reaches 1e4 in
+    # the highlight of a roughness-0.01 mirror), by 1/|v+l| in h and by 1/n.v, 1/n.l in G and the denominator:
+    #     err <= 1e-5 * max(1, 1 / (q |v+l| min(n.v, n.l)))        (measured: err q |v+l| min(nv, nl) <= 3e-6)
+    both = (a.sum(1) > 0) & (b.sum(1) > 0)
+    cond = q * hlen * np.minimum(nv, nl)
+    assert (err[both] <= TOL * np.maximum(1.0, 1.0 / cond[both])).all(), (err[both] * cond[both]).max()
+    assert err.max() < 5e-3
     assert ((a.sum(1) > 0) == (b.sum(1) > 0)).mean() > 0.9999
 
 
@@ -123,14 +131,18 @@ def test_ggx_terms(hip, oracle):
     a = hip.ggx_terms(nh, nv, nl, vh, rough, f0)
     b = oracle.unit.ggx_terms(nh, nv, nl, vh, rough, f0)
     err = rel_err(a, b, 1e-20)
-    # D = a2/(pi q^2) with q = nh^2(a2-1)+1 -> 0 as nh -> 1 at small roughness: q itself is a
-    # cancellation, so compare D where q is well conditioned and bound the rest loosely.
-    q = nh.astype(np.float64) ** 2 * (rough.astype(np.float64) ** 2 - 1) + 1
-    ok = q > 0.1
+    # D = a2/(pi q^2) with q = nh^2(a2-1)+1 -> a2 as nh -> 1: q is a cancellation, so the kernel forms it with the
+    # reference's own roundings (pt_device.h: ggx_q, product rounded before the sum, ggx.rs:11); with identical nh
+    # the two q are then the same f32 and D agrees to the rounding of the division everywhere, roughness 0.01 included
     assert err[:, :3].max() < TOL
     assert err[:, 4].max() < TOL
-    assert err[ok, 3].max() < TOL
-    assert np.quantile(err[:, 3], 0.99) < 1e-3
+    assert err[:, 3].max() < TOL, err[:, 3].max()
+    nh1 = np.concatenate([np.float32(1.0) - np.float32(2.0) ** -np.arange(1, 25, dtype=np.float32), [np.float32(1.0)]]).astype(np.float32)
+    one = np.ones_like(nh1)
+    for r in (0.01, 0.02, 0.1):                       # the highlight itself: nh -> 1 at the smallest roughness
+        a1 = hip.ggx_terms(nh1, one, one, one, one * np.float32(r), np.ones((len(nh1), 3), np.float32))
+        b1 = oracle.unit.ggx_terms(nh1, one, one, one, one * np.float32(r), np.ones((len(nh1), 3), np.float32))
+        assert rel_err(a1[:, 3], b1[:, 3], 1e-20).max() < TOL
 
 
 def test_ggx_sample(hip, oracle):
