@@ -224,6 +224,19 @@ int hippt_set_scene(hippt_context *ctx, const hippt_scene *scene);
 int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts,
                               float *d_accum, void *stream);
 
+/* hippt_render_accum_device for callers that CANNOT ALLOCATE: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc. No counterpart in the reference (its backend creates seven buffers per dispatch,
+ * src/gpu_renderer.rs:243-275). Same arguments, same kernels and the same sums as hippt_render_accum_device for
+ * scenes that render with the table megakernel (no LBVH, no HIPPT_FLAG_WAVEFRONT); the megakernel's scratch buffer
+ * (partial sums of its sample slices) is a 96 MiB array that lives in the library's device image instead of a buffer
+ * allocated on demand, so the call performs no hipMalloc / hipFree / event creation of its own. Limits: images of at
+ * most 4 194 304 pixels (two sample slices must fit; larger ones fail with HIPPT_ERR_LIMIT); at 1920x1080 the array
+ * holds 4 slices where the allocating entry point uses 8, so the sums agree with it to f32 summation order there and
+ * bit for bit on images of up to 1 048 576 pixels. Every call on a GPU shares that GPU's array: calls that overlap on
+ * one GPU (two streams, two contexts, two threads) race. Its launches are not included in hippt_kernel_time_ms. */
+int hippt_render_accum_device_noalloc(hippt_context *ctx, const hippt_options *opts,
+                                      float *d_accum, void *stream);
+
 /* Average / ACES / gamma / quantise on the device (src/renderer.rs:184-191):
  * d_accum (sums) / spp -> d_rgba (width*height*4 bytes). */
 int hippt_resolve_device(hippt_context *ctx, const float *d_accum, uint32_t spp,

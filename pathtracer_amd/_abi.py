@@ -83,7 +83,7 @@ EXPORTED_SYMBOLS = (
     "hippt_test_tonemap", "hippt_test_rng",
     "hippt_render_accum_add_f32", "hippt_resolve_f32", "hippt_checkpoint_save", "hippt_checkpoint_load",
     "hippt_render_rgba8_multi", "hippt_render_accum_f32_multi", "hippt_sample_range", "hippt_device_count",
-    "hippt_scene_dump", "hippt_test_shadow_nee",
+    "hippt_scene_dump", "hippt_test_shadow_nee", "hippt_render_accum_device_noalloc",
 )
 
 _lib = None
@@ -143,6 +143,7 @@ def load_library():
     lib.hippt_destroy.argtypes = [C.c_void_p]
     lib.hippt_set_scene.argtypes = [C.c_void_p, C.POINTER(SceneC)]
     lib.hippt_render_accum_device.argtypes = [C.c_void_p, C.POINTER(Options), C.c_void_p, C.c_void_p]
+    lib.hippt_render_accum_device_noalloc.argtypes = [C.c_void_p, C.POINTER(Options), C.c_void_p, C.c_void_p]
     lib.hippt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     lib.hippt_read_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.hippt_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]

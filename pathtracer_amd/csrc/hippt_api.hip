@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -52,6 +53,32 @@ constexpr uint64_t kPathsPerLaunch = 4ull << 30;
 const size_t kMaxLdsBlob = 64 * 1024 - pt::megakernel_static_lds();
 // Sphere count from which hippt_set_scene builds the LBVH (brute force wins below).
 constexpr uint32_t kBvhMinSpheres = 64;
+
+// ---- hippt_render_accum_device_noalloc: device scratch that exists from load time -------------------------------
+// The megakernel's only scratch buffer is the partial-sum buffer of its sample slices (launch_megakernel). The
+// ordinary entry point allocates it on demand; the no-alloc entry point uses this array instead: 96 MiB of device
+// memory per GPU the library runs on, held until the process ends.
+constexpr size_t kScratchFloats = (96ull << 20) / sizeof(float);
+constexpr uint64_t kNoAllocMaxPixels = kScratchFloats / (3 * 2);  // at least two slices must fit: 4 194 304 pixels
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) float scratch[kScratchFloats];
+// `scratch` above is a host-side stand-in, not a device address: host code uses the pointer hipGetSymbolAddress
+// returns, and every GPU has its own copy of the array at its own address.
+float *g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mutex;
+
+// Called by hippt_create with `device` current.
+int scratch_init(int device) {
+    if (device < 0 || device >= kMaxDevices) return HIPPT_OK;  // such a context has no no-alloc entry point
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return HIPPT_OK;
+    float *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr)
+        return hippt_set_error(HIPPT_ERR_DEVICE, "hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(e));
+    g_scratch_ptr[device] = ptr;
+    return HIPPT_OK;
+}
 
 // Sample slices of one megakernel launch of `c` samples per pixel: enough blocks for ~50 rounds of the chip's ~1 300
 // resident blocks (measured: 3 slices +3.4 %, 8 slices +4.6 %, 16 no more), at most `cap_floats` of partial sums.
@@ -233,6 +260,10 @@ int hippt_create(int device, hippt_context **out_ctx) {
         hippt_destroy(ctx);
         return hippt_set_error(HIPPT_ERR_DEVICE, "context setup failed: %s", hipGetErrorString(e));
     }
+    if (int rc = scratch_init(device)) {  // the device is current: this GPU's address of the no-alloc scratch array
+        hippt_destroy(ctx);
+        return rc;
+    }
     *out_ctx = ctx;
     return HIPPT_OK;
 }
@@ -380,6 +411,53 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
             HIP_TRY(pt::launch_megakernel(P, ctx->d_blob, d_accum, ctx->d_counters, count, lds, st, ctx->slice_buf, slices));
         }
         HIP_TRY(hipEventRecord(ev.second, st));
+        s0 += c;
+        cnt -= c;
+    }
+    return HIPPT_OK;
+}
+
+// The same launches as hippt_render_accum_device for table scenes (megakernel), with the partial-sum slices in this
+// GPU's copy of `scratch` instead of a buffer allocated on demand: no hipMalloc / hipFree, no event creation (these
+// launches are not timed by hippt_kernel_time_ms), nothing that allocates.
+int hippt_render_accum_device_noalloc(hippt_context *ctx, const hippt_options *opts, float *d_accum, void *stream) {
+    if (!ctx || !ctx->has_scene) return hippt_set_error(HIPPT_ERR_INVALID, "no scene set");
+    if (!d_accum) return hippt_set_error(HIPPT_ERR_INVALID, "d_accum is NULL");
+    hippt_options o{};
+    if (opts) o = *opts;
+    const uint32_t allowed = HIPPT_FLAG_COUNTERS | HIPPT_FLAG_NO_BVH | HIPPT_FLAG_TABLES_GLOBAL | HIPPT_FLAG_NO_SLICES | HIPPT_FLAG_MEGAKERNEL;
+    if (o.flags & ~allowed)
+        return hippt_set_error(HIPPT_ERR_INVALID, "hippt_render_accum_device_noalloc runs the table-scene megakernel only (flags 0x%x not supported)", o.flags & ~allowed);
+    if (ctx->bvh.n > 0 && !(o.flags & HIPPT_FLAG_NO_BVH))
+        return hippt_set_error(HIPPT_ERR_INVALID, "hippt_render_accum_device_noalloc: LBVH scenes need the queue workspace of hippt_render_accum_device");
+    if (ctx->device < 0 || ctx->device >= kMaxDevices || !g_scratch_ptr[ctx->device])
+        return hippt_set_error(HIPPT_ERR_DEVICE, "no scratch address for device %d", ctx->device);
+    float *const scratch_dev = g_scratch_ptr[ctx->device];  // the DEVICE address (hipGetSymbolAddress), never the array's name
+    pt::Params P = ctx->scene.P;
+    const uint64_t pixels = (uint64_t)P.width * P.height;
+    if (pixels > kNoAllocMaxPixels)
+        return hippt_set_error(HIPPT_ERR_LIMIT, "hippt_render_accum_device_noalloc: %ux%u = %llu pixels exceed the %llu the %zu MiB scratch array holds two sample slices of",
+                               P.width, P.height, (unsigned long long)pixels, (unsigned long long)kNoAllocMaxPixels, (kScratchFloats * sizeof(float)) >> 20);
+    uint32_t s0 = o.sample_begin;
+    uint32_t cnt = o.sample_count ? o.sample_count : (ctx->samples > s0 ? ctx->samples - s0 : 0);
+    if ((uint64_t)s0 + cnt > 0xffffffffull) return hippt_set_error(HIPPT_ERR_LIMIT, "sample range overflows 32 bits");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    P.max_depth = o.max_depth ? o.max_depth : 5u;  // MAX_DEPTH, renderer.rs:15
+    P.seed = o.seed;
+    const bool count = (o.flags & HIPPT_FLAG_COUNTERS) != 0;
+    bool lds = (size_t)P.blob_f4 * sizeof(float4) <= kMaxLdsBlob;
+    if (o.flags & HIPPT_FLAG_TABLES_GLOBAL) lds = false;
+    uint64_t per = kPathsPerLaunch / pixels;
+    if (per < 1) per = 1;
+    while (cnt > 0) {
+        const uint32_t c = (uint32_t)std::min<uint64_t>(cnt, per);
+        P.sample_begin = s0;
+        P.sample_count = c;
+        // every slice block overwrites all of its tile's in-image pixels, and pt_add_partials reads exactly the
+        // slices written here: nothing of an earlier call's contents is read, so nothing needs clearing
+        const uint32_t slices = megakernel_slices(P, c, o.flags, kScratchFloats);
+        HIP_TRY(pt::launch_megakernel(P, ctx->d_blob, d_accum, ctx->d_counters, count, lds, st, scratch_dev, slices));
         s0 += c;
         cnt -= c;
     }

@@ -114,6 +114,12 @@ class Context:
         _abi.check(self.lib.hippt_render_accum_device(self.h, C.byref(o), C.c_void_p(d_accum_ptr),
                                                       C.c_void_p(stream)), self.lib)
 
+    def render_accum_device_noalloc(self, d_accum_ptr, sample_begin, sample_count, seed=0, max_depth=0, flags=0, stream=0):
+        """hippt_render_accum_device_noalloc: the same launches with the library's static device scratch (no allocation)."""
+        o = _opts(sample_begin, sample_count, max_depth, seed, flags, 0)
+        _abi.check(self.lib.hippt_render_accum_device_noalloc(self.h, C.byref(o), C.c_void_p(d_accum_ptr),
+                                                              C.c_void_p(stream)), self.lib)
+
     def resolve_device(self, d_accum_ptr, spp, d_rgba_ptr, stream=0):
         _abi.check(self.lib.hippt_resolve_device(self.h, C.c_void_p(d_accum_ptr), spp, C.c_void_p(d_rgba_ptr),
                                                  C.c_void_p(stream)), self.lib)
