@@ -128,7 +128,8 @@ int pack_scene(const hippt_scene *sc, PackedScene &out) {
     P.mat_off = P.aux_off + P.n_sph + P.n_pl;
     P.light_off = P.mat_off + sc->n_materials * pt::MAT_F4;
     P.cam_off = P.light_off + sc->n_lights * pt::LIGHT_F4;
-    P.blob_f4 = P.cam_off + pt::CAM_F4;
+    P.cull_off = P.cam_off + pt::CAM_F4;
+    P.blob_f4 = P.cull_off + sc->n_lights * sc->n_planes;
     P.tiles_x = (sc->width + 15u) / 16u;
     out.blob.assign(P.blob_f4, mk4(0, 0, 0, 0));
     {
@@ -190,6 +191,28 @@ int pack_scene(const hippt_scene *sc, PackedScene &out) {
         q[2] = mk4(l.v[0], l.v[1], l.v[2], 0);
         q[3] = mk4(l.intensity[0], l.intensity[1], l.intensity[2], 0);
         q[4] = mk4(cx * inv, cy * inv, cz * inv, 0);
+        // Which side of each plane the light's rectangle lies on (pt_device.h: occluded_multi, CULL). Light points are
+        // pos + u e1 + v e2 with e in [-1/2, 1/2) (renderer.rs:37-39): the four corners bound (y - p).n. The margin
+        // keeps the f32 arithmetic of the kernel (and of the light points it forms) well inside the decision.
+        for (uint32_t k = 0; k < sc->n_planes; ++k) {
+            const hippt_plane &p = sc->planes[pi[k]];
+            double lo = INFINITY, hi = -INFINITY, scale = 0.0;
+            for (int c = 0; c < 4; ++c) {
+                const double e1 = (c & 1) ? 0.5 : -0.5, e2 = (c & 2) ? 0.5 : -0.5;
+                double g = 0.0, ext = 0.0;
+                for (int a = 0; a < 3; ++a) {
+                    const double y = (double)l.pos[a] + (double)l.u[a] * e1 + (double)l.v[a] * e2;
+                    g += (y - (double)p.point[a]) * (double)p.normal[a];
+                    ext = std::max(ext, std::max(std::fabs(y), std::fabs((double)p.point[a])));
+                }
+                lo = std::min(lo, g);
+                hi = std::max(hi, g);
+                scale = std::max(scale, ext);
+            }
+            const double margin = 1e-4 * (1.0 + scale);
+            const float side = lo > margin ? 1.0f : (hi < -margin ? -1.0f : 0.0f);
+            out.blob[P.cull_off + (size_t)i * sc->n_planes + k] = mk4(std::isfinite(lo) && std::isfinite(hi) ? side : 0.0f, 0, 0, 0);
+        }
     }
     return HIPPT_OK;
 }

@@ -22,6 +22,8 @@ namespace pt {
 //   lights   : n_light x 5 {pos,area} {u,0} {v,0} {intensity,0} {normal,0}
 //   camera   : 5  {pos,aspect} {right,scale} {up,aperture} {forward,focus} {1/width,1/height,0,0}
 //              (in the blob, not in Params: read once per path, and 22 fewer SGPRs live across the trace loop)
+//   cull     : n_light x n_pl  {side,0,0,0}: +1 / -1 if the whole rectangle of light i lies strictly on the
+//              positive / negative side of plane j ((y - p).n > 0 / < 0 for its four corners), 0 if it straddles it
 constexpr int MAT_F4 = 2;
 constexpr int LIGHT_F4 = 5;
 constexpr int CAM_F4 = 5;
@@ -29,7 +31,7 @@ constexpr int CAM_F4 = 5;
 struct Params {
     uint32_t width, height;
     uint32_t n_sph, n_pl, n_mat, n_light;
-    uint32_t sph_off, pl_off, aux_off, mat_off, light_off, cam_off;  // float4 offsets into the blob
+    uint32_t sph_off, pl_off, aux_off, mat_off, light_off, cam_off, cull_off;  // float4 offsets into the blob
     uint32_t blob_f4;             // blob size in float4
     uint32_t sample_begin, sample_count, max_depth, seed;
     uint32_t tiles_x;             // 16x16 pixel tiles per row
@@ -101,6 +103,10 @@ struct Rng {
         s1 = mix32(c + 0x9e3779b9u) | 1u;
     }
     __device__ __forceinline__ float gen() {
+#ifdef PT_RNG_LCG_EXPERIMENT
+        s0 = s0 * 2891336453u + s1;
+        return (float)(s0 >> 8) * 5.9604644775390625e-08f;
+#endif
         uint32_t r = s0 + s1;
         uint32_t t = s1 ^ s0;
         s0 = __builtin_amdgcn_bitop3_b32(__builtin_rotateleft32(s0, 26), t, t << 9, 0x96);  // a ^ b ^ c in one v_bitop3_b32
@@ -370,11 +376,23 @@ __device__ __forceinline__ void object_shadow(const Tbl &tbl, const Params &P, u
 // LEARN: also report the object that blocks ALL NS rays of the most lanes (`dominant`, an object index as
 // object_shadow takes it, and on how many of the calling lanes, `dominant_lanes`); both are wave-uniform and
 // formed with scalar instructions from the compare masks.
-template <class Tbl, int NS, bool COUNT, bool LEARN = false>
+//
+// CULL (cull_row = float4 offset of this light's rows of the cull table, `active` = this lane's x / l are real): a
+// plane whose positive side holds the whole light can only block a ray that starts on its negative side, so the wave
+// skips the plane's row unless some lane stands there. Exactly the decisions of the full test: a hit needs
+// tp = Dn / (n.l) > eps + 1e-4 (plane_shadow_row), i.e. Dn and n.l of one sign and |Dn| > (eps + 1e-4) |n.l|;
+//  - a lane on the light's side (Dn side <= 0) has tp <= 0, or meets the plane BEHIND the light point (the zero of
+//    (y - p).n along x -> light lies beyond the light when both ends are on one side), which fails t < 0.9995 dist;
+//  - a lane on the far side is a candidate when |Dn| > 0.95 (eps + 1e-4) |n.l| for one of its rays (conservative:
+//    5 % against the ~1e-7 of v_rcp_f32). Lanes that stand ON the plane with Dn = +-1e-7 of rounding noise — half of
+//    all lanes on a floor or a wall — are candidates only at |n.l| < ~2e-3, so the skip still fires.
+// On scene.example the four room planes never block the light inside the room: 3/4 of the plane rows of the open
+// light's loop go.
+template <class Tbl, int NS, bool COUNT, bool LEARN = false, bool CULL = false>
 __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, F3 x, float eps, const F3 (&l)[NS],
                                                const float (&tmax)[NS], bool (&occ)[NS], uint32_t &n_sph_tests,
                                                uint32_t &n_pl_tests, bool spheres = true, uint32_t *dominant = nullptr,
-                                               uint32_t *dominant_lanes = nullptr) {
+                                               uint32_t *dominant_lanes = nullptr, uint32_t cull_row = 0u, bool active = true) {
     const uint32_t n_sph = spheres ? P.n_sph : 0u;  // false: the caller has tested the spheres (BVH) and set occ[]
     if (spheres) {
 #pragma unroll
@@ -416,8 +434,22 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
 #pragma unroll 1
     for (uint32_t j = 0; j < P.n_pl; ++j) {
         uint32_t o = P.pl_off + j * 3u;
+        const float4 q0 = tbl.ld(o), q1 = tbl.ld(o + 1);
+        if constexpr (CULL) {
+            const float side = tbl.ld(cull_row + j).x;  // wave-uniform
+            if (side != 0.0f) {
+                const F3 n = F3{q0.w, q1.x, q1.y};
+                const float Dn = -dot(x - f3(q0), n);
+                const float thr = -0.95f * (eps + 1e-4f);
+                float m = fmaf(fabsf(dot(n, l[0])), thr, fabsf(Dn));
+#pragma unroll
+                for (int s = 1; s < NS; ++s) m = fmaxf(m, fmaf(fabsf(dot(n, l[s])), thr, fabsf(Dn)));
+                const bool cand = active & (Dn * side > 0.0f) & (m > 0.0f);
+                if (ballot64(cand) == 0ull) continue;
+            }
+        }
         bool hit[NS];
-        plane_shadow_row<NS>(tbl.ld(o), tbl.ld(o + 1), tbl.ld(o + 2), x, eps, l, q, hit);
+        plane_shadow_row<NS>(q0, q1, tbl.ld(o + 2), x, eps, l, q, hit);
         fold(hit, P.n_sph + j);
     }
     if (COUNT) {

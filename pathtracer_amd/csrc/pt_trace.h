@@ -13,6 +13,10 @@ namespace pt {
 #ifndef PT_HINT_SLACK
 #define PT_HINT_SLACK 128u
 #endif
+// 0: shadow loops test every plane row (A/B builds, tools/build_variant.sh)
+#ifndef PT_CULL
+#define PT_CULL 1
+#endif
 constexpr uint32_t kHintLights = 8;  // lights that keep a remembered occluder
 constexpr uint32_t kNoHint = 0xffffffffu;
 constexpr uint32_t kPairCap = 128;   // pending shadow rays: < 64 left over + at most 64 new ones per light
@@ -117,8 +121,9 @@ struct Tracer {
                     bump(HIPPT_C_SHADOW_SPHERE_TESTS, nt);
                 }
             }
-            occluded_multi<Tbl, 4, COUNT>(tbl, P, x, 1e-4f, l, tmax, occ, cnt[HIPPT_C_SHADOW_SPHERE_TESTS],
-                                          cnt[HIPPT_C_SHADOW_PLANE_TESTS], !BVH);
+            occluded_multi<Tbl, 4, COUNT, false, PT_CULL != 0>(tbl, P, x, 1e-4f, l, tmax, occ, cnt[HIPPT_C_SHADOW_SPHERE_TESTS],
+                                                       cnt[HIPPT_C_SHADOW_PLANE_TESTS], !BVH, nullptr, nullptr,
+                                                       P.cull_off + li * P.n_pl);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (!occ[s]) {
@@ -243,7 +248,8 @@ struct Tracer {
             if (full && nee) {
                 bool occ[4];
                 uint32_t dom, dom_lanes;
-                occluded_multi<Tbl, 4, false, true>(tbl, P, x, 1e-4f, l, tmax, occ, dummy0, dummy1, true, &dom, &dom_lanes);
+                occluded_multi<Tbl, 4, false, true, PT_CULL != 0>(tbl, P, x, 1e-4f, l, tmax, occ, dummy0, dummy1, true, &dom, &dom_lanes,
+                                                          P.cull_off + li * P.n_pl);
                 // worth remembering if the lanes it leaves over fit a batch: at most 4 rays each
                 if (li < kHintLights && dom_lanes != 0u && (n_nee - dom_lanes) * 4u <= PT_HINT_SLACK)
                     __hip_atomic_store(&sh->hint[li], dom, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
