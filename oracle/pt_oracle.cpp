@@ -99,12 +99,10 @@ struct Rng {
         s1 = mix32(c + 0x9e3779b9u) | 1u;
     }
     // rand's Standard f32: 24 random bits scaled by 2^-24, in [0,1).
+    // (32-bit LCG with the stream's own odd increment; top 24 bits of the new state)
     float gen() {
-        uint32_t r = s0 + s1;
-        uint32_t t = s1 ^ s0;
-        s0 = rotl32(s0, 26) ^ t ^ (t << 9);
-        s1 = rotl32(t, 13);
-        return (float)(r >> 8) * (1.0f / 16777216.0f);
+        s0 = s0 * 2891336453u + s1;
+        return (float)(s0 >> 8) * (1.0f / 16777216.0f);
     }
 };
 

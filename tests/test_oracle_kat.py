@@ -220,6 +220,21 @@ def test_rng_distribution(oracle):
     h2 = np.histogram2d(x[0::2], x[1::2], bins=16, range=[[0, 1], [0, 1]])[0]
     e = len(x) / 2 / 256
     assert ((h2 - e) ** 2 / e).sum() < 400                       # 255 dof
+    # an LCG's weak spot is the lattice of consecutive outputs: serial correlations up to lag 16 (one light's 8 draws
+    # and the next light's) and the 3-D and 4-D cells of consecutive triples / quadruples must be evenly filled
+    for lag in range(2, 17):
+        assert abs(np.corrcoef(x[:-lag], x[lag:])[0, 1]) < 5e-3, lag
+    n3 = len(x) // 3 * 3
+    c3 = (x[:n3].reshape(-1, 3) * 8).astype(int)
+    h3 = np.bincount(c3[:, 0] * 64 + c3[:, 1] * 8 + c3[:, 2], minlength=512)
+    assert ((h3 - n3 / 3 / 512) ** 2 / (n3 / 3 / 512)).sum() < 700     # 511 dof: P(chi2 > 700) ~ 1e-8
+    c4 = (x.reshape(-1, 4) * 4).astype(int)
+    h4 = np.bincount(c4[:, 0] * 64 + c4[:, 1] * 16 + c4[:, 2] * 4 + c4[:, 3], minlength=256)
+    assert ((h4 - len(x) / 4 / 256) ** 2 / (len(x) / 4 / 256)).sum() < 400
+    # fine structure of pairs: 256 x 256 cells, 2 expected per cell on average -> compare the count distribution's
+    # variance with Poisson's (a coarse lattice would leave most cells empty)
+    h2f = np.histogram2d(x[0::2], x[1::2], bins=256, range=[[0, 1], [0, 1]])[0]
+    assert abs(h2f.var() / h2f.mean() - 1.0) < 0.05
     # first draws of neighbouring streams (pixel+1, sample+1) are uncorrelated
     firsts = np.array([oracle.unit.rng(0, p, s, 1)[0] for p in range(64) for s in range(64)], np.float64)
     assert abs(firsts.mean() - 0.5) < 0.02
