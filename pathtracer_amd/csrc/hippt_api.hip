@@ -111,6 +111,7 @@ int pack_scene(const hippt_scene *sc, PackedScene &out) {
     if ((uint64_t)sc->width * sc->height > (1ull << 31))
         return hippt_set_error(HIPPT_ERR_LIMIT, "image %ux%u exceeds 2^31 pixels", sc->width, sc->height);
     uint32_t n_obj = sc->n_spheres + sc->n_planes;
+    if (sc->n_materials > (1u << 23)) return hippt_set_error(HIPPT_ERR_LIMIT, "%u materials exceed 2^23", sc->n_materials);
     if ((sc->n_spheres && !sc->spheres) || (sc->n_planes && !sc->planes) || (sc->n_lights && !sc->lights) ||
         (sc->n_materials && !sc->materials))
         return hippt_set_error(HIPPT_ERR_INVALID, "NULL table with non-zero count");

@@ -475,6 +475,7 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
 __device__ __forceinline__ F3 reflect(F3 v, F3 n) { return madd(v, n, -2.0f * dot(v, n)); }
 // ggx.rs:7-9
 __device__ __forceinline__ F3 fresnel_schlick(float cos_theta, F3 f0) {
+#pragma clang fp contract(off)  // explicit fmaf only: every inlined copy rounds the same way (see nee_eval)
     float w = pow5(1.0f - cos_theta);
     return F3{fmaf(1.0f - f0.x, w, f0.x), fmaf(1.0f - f0.y, w, f0.y), fmaf(1.0f - f0.z, w, f0.z)};
 }
@@ -594,6 +595,7 @@ struct ShadeK {  // per-vertex invariants of renderer.rs:59,63,65-66,72
     float spec_v;   // a^2 n.v / (pi (n.v (1 - k) + k)): the n.v-only factors of D G
 };
 __device__ __forceinline__ ShadeK make_shade(F3 n, F3 v, const Mat &m) {
+#pragma clang fp contract(off)  // explicit fmaf only, as nee_eval
     ShadeK s;
     s.n = n;
     s.v = v;
@@ -616,8 +618,13 @@ __device__ __forceinline__ ShadeK make_shade(F3 n, F3 v, const Mat &m) {
 // The specular term D G / (4 n.v n.l + 1e-6) (ggx.rs:10-18, renderer.rs:65-70) is formed over ONE common
 // denominator, q^2 (n.l (1 - k) + k) (4 n.v n.l + 1e-6), with the n.v-only factors hoisted into ShadeK:
 // one v_rcp_f32 per sample instead of four (transcendentals issue at quarter rate).
+// Contraction is spelt out (explicit fmaf, none implied): the lights loop evaluates a sample either in its own lane
+// or, for the rays parked on the wave's list, later in another lane (Tracer::process_pairs); which of the two depends
+// on what the wave has seen so far, and the two inlined copies must agree bit for bit (a roughness-0.01 highlight
+// amplifies a last-bit difference 1e4 times; chunked and one-shot renders are compared to 2e-6).
 __device__ __forceinline__ F3 nee_eval(const ShadeK &s, F3 l, float inv_dist2, F3 light_n, float light_area,
                                        F3 intensity, bool &lit) {
+#pragma clang fp contract(off)
     // .max(0.0) of renderer.rs:49,53 is implied by the two `> 0` tests that follow it (:50,:55)
     float n_dot_l = dot(s.n, l);
     float cos_l = -dot(l, light_n);
@@ -632,7 +639,8 @@ __device__ __forceinline__ F3 nee_eval(const ShadeK &s, F3 l, float inv_dist2, F
     float den = (q * q) * fmaf(n_dot_l, 1.0f - s.k, s.k) * fmaf(s.four_nv, n_dot_l, 1e-6f);
     float spec = (s.spec_v * n_dot_l) * rcp(den);
     F3 kd = F3{1.0f - f.x, 1.0f - f.y, 1.0f - f.z};
-    F3 brdf = s.diffuse_over_pi * kd + f * spec;
+    F3 brdf = F3{fmaf(s.diffuse_over_pi.x, kd.x, f.x * spec), fmaf(s.diffuse_over_pi.y, kd.y, f.y * spec),
+                 fmaf(s.diffuse_over_pi.z, kd.z, f.z * spec)};
     float w = n_dot_l * (light_area * falloff);
     return brdf * intensity * w;
 }

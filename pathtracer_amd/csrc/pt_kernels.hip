@@ -135,6 +135,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
         int kind = 0;  // 0: miss or glass (no NEE), 1: opaque surface, 2: scatter point inside the medium
         F3 x = F3{0, 0, 0}, n = F3{0.0f, 1.0f, 0.0f};  // :273: scatter points shade with a fixed "up" normal (Q11)
         int next_media = media;
+        uint32_t nee_mat = (uint32_t)media;  // material id of m at a vertex that is lit
         if (t_media < h.t) {  // :269
             tr.bump(HIPPT_C_SCATTER_EVENTS);
             x = point_at_ref(ro, rd, t_media);
@@ -146,6 +147,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
             uint32_t mid, order;
             tr.finish(ray, h, x, n, mid, order);
             m = load_mat(tbl, P.mat_off, mid);
+            nee_mat = mid;
             if (m.density > 0.0f) next_media = (dot(-rd, n) > 0.0f) ? (int)mid : -1;  // :301-305
             T = T * A;
             if (m.ior > 1.0f && m.metallic < 0.1f) {  // :307 glass
@@ -160,7 +162,7 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
         }
 
         F3 D;
-        if constexpr (kSharedNee) tr.direct_light_shared(kind != 0, x, n, -rd, m, rng, T, psum, my_pl, &wl->nee, wl->acc);
+        if constexpr (kSharedNee) tr.direct_light_shared(kind != 0, x, n, -rd, m, nee_mat, rng, T, psum, my_pl, &wl->nee, wl->acc);
         if (kind != 0) {
             if constexpr (!kSharedNee) {
                 D = tr.direct_light(x, make_shade(n, -rd, m), rng);

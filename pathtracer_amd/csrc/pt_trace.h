@@ -19,9 +19,9 @@ namespace pt {
 #endif
 constexpr uint32_t kHintLights = 8;  // lights that keep a remembered occluder
 constexpr uint32_t kNoHint = 0xffffffffu;
-constexpr uint32_t kPairCap = 128;   // pending shadow rays: < 64 left over + at most 64 new ones per light
+constexpr uint32_t kPairCap = 64;    // pending shadow rays (a light whose rays do not fit beside them has them tested first)
 constexpr uint32_t kPairBatch = 64;
-constexpr uint32_t kPairWords = 11;  // x, l, tmax, the radiance the ray carries if it arrives, pixel slot
+constexpr uint32_t kPairWords = 18;  // x, l, tmax, 1/dist2, n, v, T, {material | pixel slot << 23 | light << 29}
 struct NeeShare {
     uint32_t hint[kHintLights];  // per light: the object that last blocked all 4 samples of most lanes
     uint32_t pending;            // rays in the list
@@ -162,10 +162,21 @@ struct Tracer {
             bool po[1];
             occluded_multi<Tbl, 1, false>(tbl, P, px, 1e-4f, pl, pt, po, d0, d1);
             if (!po[0]) {
-                float *a = acc + __float_as_uint(pr[10 * kPairCap]) * 3u;
-                __hip_atomic_fetch_add(a + 0, pr[7 * kPairCap], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(a + 1, pr[8 * kPairCap], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(a + 2, pr[9 * kPairCap], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // the ray arrives: renderer.rs:49-77 for it, here rather than in the lane that drew it — on the list
+                // the wave's few survivors of a mostly blocked light sit side by side
+                const uint32_t w = __float_as_uint(pr[17 * kPairCap]);
+                const Mat m = load_mat(tbl, P.mat_off, w & 0x7fffffu);
+                const ShadeK sk = make_shade(F3{pr[8 * kPairCap], pr[9 * kPairCap], pr[10 * kPairCap]},
+                                             F3{pr[11 * kPairCap], pr[12 * kPairCap], pr[13 * kPairCap]}, m);
+                const uint32_t o = P.light_off + (w >> 29) * LIGHT_F4;
+                const float4 l0 = tbl.ld(o), l3 = tbl.ld(o + 3), l4 = tbl.ld(o + 4);
+                bool lit;
+                F3 c = nee_eval(sk, pl[0], pr[7 * kPairCap], f3(l4), l0.w, f3(l3), lit);
+                c = F3{pr[14 * kPairCap], pr[15 * kPairCap], pr[16 * kPairCap]} * c * 0.25f;  // :82, and the path throughput (:285 / :325)
+                float *a = acc + ((w >> 23) & 63u) * 3u;
+                __hip_atomic_fetch_add(a + 0, c.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(a + 1, c.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(a + 2, c.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         wave_lds_sync();
@@ -176,9 +187,10 @@ struct Tracer {
         uint32_t n = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (n) process_pairs(sh, acc, 0u, n);
     }
-    __device__ __forceinline__ void direct_light_shared(bool nee, F3 x, F3 n, F3 v, const Mat &m, Rng &rng, F3 T, F3 &psum,
-                                                        uint32_t pix, NeeShare *sh, float *acc) {
+    __device__ __forceinline__ void direct_light_shared(bool nee, F3 x, F3 n, F3 v, const Mat &m, uint32_t mat_id, Rng &rng, F3 T,
+                                                        F3 &psum, uint32_t pix, NeeShare *sh, float *acc) {
         static_assert(!COUNT && !BVH, "the counting and LBVH kernels use direct_light");
+        static_assert(kHintLights <= 8, "the list word keeps the light in 3 bits");
         const uint32_t n_nee = (uint32_t)__popcll(ballot64(nee));
         if (n_nee == 0u) return;
         // not kept in a register across trips: a lane whose pool item lies outside the image skips the trip
@@ -215,8 +227,6 @@ struct Tracer {
                 h = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->hint[li], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             bool full = true;
             uint32_t surv = 0;  // bit s: evaluate sample s (hinted: lit from the front and not blocked by the remembered object)
-            uint32_t hinted_n = 0, base[4];
-            unsigned long long bs[4];
             if (h != kNoHint) {
                 if (nee) {
                     bool hit[4];
@@ -228,17 +238,41 @@ struct Tracer {
                 const unsigned long long b0 = ballot64((surv & 1u) != 0u), b1 = ballot64((surv & 2u) != 0u),
                                          b2 = ballot64((surv & 4u) != 0u), b3 = ballot64((surv & 8u) != 0u);
                 const uint32_t n0 = (uint32_t)__popcll(b0), n1 = n0 + (uint32_t)__popcll(b1), n2 = n1 + (uint32_t)__popcll(b2),
-                               n = n2 + (uint32_t)__popcll(b3);
-                if (n <= kPairBatch) {
+                               n_surv = n2 + (uint32_t)__popcll(b3);
+                if (n_surv <= kPairBatch) {
                     full = false;
-                    hinted_n = n;
-                    base[0] = pending, base[1] = pending + n0, base[2] = pending + n1, base[3] = pending + n2;
-                    bs[0] = b0, bs[1] = b1, bs[2] = b2, bs[3] = b3;
-                    if (n == 0u) NEE_DIAG(li * 4u + 1u, 1);
-                    if (n != 0u) {
+                    if (n_surv == 0u) NEE_DIAG(li * 4u + 1u, 1);
+                    if (n_surv != 0u) {
                         NEE_DIAG(li * 4u + 2u, 1);
-                        NEE_DIAG(li * 4u + 3u, n);
+                        NEE_DIAG(li * 4u + 3u, n_surv);
+                        if (pending + n_surv > kPairCap) {  // no room beside the rays already parked: test those now
+                            process_pairs(sh, acc, 0u, pending);
+                            pending = 0u;
+                        }
+                        const uint32_t base[4] = {pending, pending + n0, pending + n1, pending + n2};
+                        const unsigned long long bs[4] = {b0, b1, b2, b3};
+                        const float word = __uint_as_float(mat_id | (pix << 23) | (li << 29));  // li < kHintLights = 8, materials < 2^23 (host check)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            if (surv & (1u << s)) {
+                                float *pr = sh->pair + base[s] + rank_in(bs[s]);
+                                pr[0] = x.x, pr[kPairCap] = x.y, pr[2 * kPairCap] = x.z;
+                                pr[3 * kPairCap] = l[s].x, pr[4 * kPairCap] = l[s].y, pr[5 * kPairCap] = l[s].z;
+                                pr[6 * kPairCap] = tmax[s], pr[7 * kPairCap] = id2[s];
+                                pr[8 * kPairCap] = n.x, pr[9 * kPairCap] = n.y, pr[10 * kPairCap] = n.z;
+                                pr[11 * kPairCap] = v.x, pr[12 * kPairCap] = v.y, pr[13 * kPairCap] = v.z;
+                                pr[14 * kPairCap] = T.x, pr[15 * kPairCap] = T.y, pr[16 * kPairCap] = T.z;
+                                pr[17 * kPairCap] = word;
+                            }
+                        }
+                        pending += n_surv;
+                        if (pending == kPairBatch) {
+                            process_pairs(sh, acc, 0u, kPairBatch);
+                            pending = 0u;
+                        }
+                        __hip_atomic_store(&sh->pending, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
+                    surv = 0;  // nothing left to evaluate in this lane
                 } else {  // the remembered object no longer blocks most of the wave's samples
                     NEE_DIAG(12u + li, 1);
                     __hip_atomic_store(&sh->hint[li], kNoHint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -257,8 +291,7 @@ struct Tracer {
                 for (int s = 0; s < 4; ++s)
                     if (!occ[s]) surv |= 1u << s;
             }
-            // ONE evaluation site for both cases (two inlined copies could be contracted differently, and a
-            // roughness-0.01 highlight amplifies a last-bit difference 1e4 times): surv = samples to evaluate
+            // the ordinary loop's survivors are evaluated where they stand
             if (surv != 0u) {
                 // the shading constants are formed here, per light, rather than carried through the shadow tests in
                 // 10 registers the kernel does not have (5 waves per SIMD: 96 VGPRs)
@@ -268,29 +301,10 @@ struct Tracer {
                 for (int s = 0; s < 4; ++s) {
                     if (surv & (1u << s)) {
                         bool lit;
-                        F3 c = nee_eval(sk, l[s], id2[s], f3(l4), l0.w, f3(l3), lit);
-                        if (full) {
-                            contrib = contrib + c;
-                        } else {
-                            c = T * c * 0.25f;  // :82, and the path throughput (:285 / :325)
-                            float *pr = sh->pair + base[s] + rank_in(bs[s]);
-                            pr[0] = x.x, pr[kPairCap] = x.y, pr[2 * kPairCap] = x.z;
-                            pr[3 * kPairCap] = l[s].x, pr[4 * kPairCap] = l[s].y, pr[5 * kPairCap] = l[s].z;
-                            pr[6 * kPairCap] = tmax[s];
-                            pr[7 * kPairCap] = c.x, pr[8 * kPairCap] = c.y, pr[9 * kPairCap] = c.z;
-                            pr[10 * kPairCap] = __uint_as_float(pix);
-                        }
+                        contrib = contrib + nee_eval(sk, l[s], id2[s], f3(l4), l0.w, f3(l3), lit);
                     }
                 }
                 psum = madd(psum, T * contrib, 0.25f);  // :82 and :285 / :325, straight into the path's sum
-            }
-            if (hinted_n != 0u) {
-                pending += hinted_n;
-                if (pending >= kPairBatch) {
-                    pending -= kPairBatch;
-                    process_pairs(sh, acc, pending, kPairBatch);
-                }
-                __hip_atomic_store(&sh->pending, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
