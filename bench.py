@@ -50,7 +50,7 @@ CONFIGS = {
 
 # Counter figures that cannot be read inside this process (rocprofv3 --pmc runs of this same command, kept under
 # profiles/). Keyed by (config, width, height, spp per launch, flags, max_depth); anything else reports null.
-PMC_INDEX = os.path.join(ROOT, "profiles", "pmc_index.json")
+PMC_INDEX = os.path.join(ROOT, "pathtracer_amd", "pmc_index.json")  # travels to the GPU box (profiles/ does not)
 
 
 def pmc_lookup(config, W, H, spp_launch, flags, max_depth):

@@ -162,8 +162,11 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
         }
 
         F3 D;
-        if constexpr (kSharedNee) tr.direct_light_shared(kind != 0, x, n, -rd, m, nee_mat, rng, T, psum, my_pl, &wl->nee, wl->acc);
+        if constexpr (kSharedNee) tr.direct_light_shared(kind != 0, x, n, -rd, nee_mat, rng, T, psum, my_pl, &wl->nee, wl->acc);
         if (kind != 0) {
+            // the shared lights loop reads the material from the tables itself; so does the lobe sampling below, and
+            // no material lives in registers across the loop
+            if constexpr (kSharedNee) m = load_mat(tbl, P.mat_off, nee_mat);
             if constexpr (!kSharedNee) {
                 D = tr.direct_light(x, make_shade(n, -rd, m), rng);
                 psum = psum + T * D;  // :285 / :325

@@ -187,7 +187,7 @@ struct Tracer {
         uint32_t n = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (n) process_pairs(sh, acc, 0u, n);
     }
-    __device__ __forceinline__ void direct_light_shared(bool nee, F3 x, F3 n, F3 v, const Mat &m, uint32_t mat_id, Rng &rng, F3 T,
+    __device__ __forceinline__ void direct_light_shared(bool nee, F3 x, F3 n, F3 v, uint32_t mat_id, Rng &rng, F3 T,
                                                         F3 &psum, uint32_t pix, NeeShare *sh, float *acc) {
         static_assert(!COUNT && !BVH, "the counting and LBVH kernels use direct_light");
         static_assert(kHintLights <= 8, "the list word keeps the light in 3 bits");
@@ -294,8 +294,16 @@ struct Tracer {
             // the ordinary loop's survivors are evaluated where they stand
             if (surv != 0u) {
                 // the shading constants are formed here, per light, rather than carried through the shadow tests in
-                // 10 registers the kernel does not have (5 waves per SIMD: 96 VGPRs)
-                const ShadeK sk = make_shade(n, v, m);
+                // 10 registers the kernel does not have (5 waves per SIMD: 96 VGPRs). The empty asm statements make
+                // their inputs opaque, or the optimiser hoists the whole of make_shade out of the lights loop again
+                // (loop-invariant code motion) and spills to make room for it.
+                // The material is read again from the tables by its id (two wave-wide LDS reads), so that its 8
+                // registers are free during the shadow tests.
+                F3 n_here = n;
+                uint32_t id_here = mat_id;
+                asm volatile("" : "+v"(n_here.x), "+v"(id_here));
+                const Mat m_here = load_mat(tbl, P.mat_off, id_here);
+                const ShadeK sk = make_shade(n_here, v, m_here);
                 F3 contrib = F3{0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
