@@ -300,18 +300,56 @@ def main():
                                  "rank's share of a step) / mean trace-kernel duration from HIP events on the launch stream; "
                                  "the path is VALU-bound (no MFMA)"},
         }
-        if pmc:  # figures from committed rocprofv3 --pmc passes of this command: NOT measured in this run
-            r = out["roofline"]
-            r["traffic"] = pmc.get("traffic_bytes")
-            r["traffic_source"] = f"{pmc.get('source')} (rocprofv3 --pmc pass of this command on an earlier run; not measured in this run)"
-            for k in ("hw_flop_frac", "lanes_active", "l2_hit_rate"):
-                if k in pmc:
-                    r[k] = pmc[k]
-            if "note" in pmc:
-                r["pmc_note"] = pmc["note"]
+        pmc_pending = pmc
         if lbvh and kernel == "wavefront+lbvh":
+            # The LBVH queue pipeline is bound by what its rays FETCH, not by arithmetic (PMC: the traversal kernels wait on
+            # memory two thirds of their cycles, profiles/r0*_c4_*): its roofline is bytes against the L2 rate of the
+            # guide. Algorithmic bytes of a step, from an untimed pass that counts the traversal's fetches
+            # (HIPPT_FLAG_TRAVERSAL_STATS) and from the event counters above; layouts in pt_wfqueue.h / DESIGN.md §3:
+            with torch.cuda.stream(stream):
+                accum.zero_()
+                ctx.render_accum_device(accum.data_ptr(), s0, cnt, seed=0, max_depth=args.max_depth,
+                                        flags=args.flags | _abi.FLAG_TRAVERSAL_STATS, stream=stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            ts = ctx.read_traversal_stats()
+            ctx.kernel_time_ms()
+            L = len(scene.lights)
+            E, V = cn["extend_rays"], cn["nee_vertices"]
+            # nodes of the tree's first levels come from the block's LDS copy: not memory traffic
+            trav = sum((ts[k]["nodes"] - ts[k]["nodes_from_lds"]) * 32 + ts[k]["leaf_fetches"] * 32 + ts[k]["aux_rows"] * 16
+                       for k in ("closest", "any"))
+            rays_io = ts["closest"]["rays"] * (24 + 8) + ts["any"]["rays"] * (4 + 4 + 16 + 12 + 1)
+            queues = E * (76 + 68) + V * (84 + 40 + L * 84 + 84 + L * 84)
+            step_bytes = trav + rays_io + queues
+            gbs = step_bytes / (k_ms * launches_per_step * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "l2", "achieved": round(gbs, 1), "peak": L2_PEAK_TBS * 1e3, "unit": "GB/s",
+                "frac": round(gbs / (L2_PEAK_TBS * 1e3), 4), "traffic": None,
+                "kernel_ms": round(k_ms, 3), "launches_per_step": launches_per_step,
+                "bytes_per_step": {"traversal_fetches": trav, "ray_io": rays_io, "queue_entries": queues},
+                "per_ray": {k: {"nodes": round(ts[k]["nodes"] / max(ts[k]["rays"], 1), 1),
+                                "nodes_from_lds": round(ts[k]["nodes_from_lds"] / max(ts[k]["rays"], 1), 1),
+                                "leaf_fetches": round(ts[k]["leaf_fetches"] / max(ts[k]["rays"], 1), 1),
+                                "bytes": round(((ts[k]["nodes"] - ts[k]["nodes_from_lds"]) * 32 + ts[k]["leaf_fetches"] * 32 + ts[k]["aux_rows"] * 16) / max(ts[k]["rays"], 1))}
+                            for k in ("closest", "any")},
+                "valu_fp32": {"achieved_tflops": round(achieved, 3), "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4)},
+                "note": "rank 0's GPU: algorithmic bytes of a step (32 B per BVH node visited, 32 B per leaf fetch of two spheres, "
+                        "16 B per aux row, ray records, queue entries read and written by the logic / sampling / shading kernels) "
+                        "/ duration of the step's kernels from HIP events on the launch stream, against the aggregate L2 rate of "
+                        "MI355X_MICROARCH.md (34.5 TB/s); the node and sphere fetches are per-lane 16-byte gathers, most of which "
+                        "hit the vector L1",
+            }
             out["flop_note"] = ("event counts come from the BVH megakernel (HIPPT_FLAG_COUNTERS); its traversal visits "
                                 "spheres in another order than the queue kernels, so sphere-test counts differ slightly")
+        if pmc_pending:  # figures from committed rocprofv3 --pmc passes of this command: NOT measured in this run
+            r = out["roofline"]
+            r["traffic"] = pmc_pending.get("traffic_bytes")
+            r["traffic_source"] = f"{pmc_pending.get('source')} (rocprofv3 --pmc pass of this command on an earlier run; not measured in this run)"
+            for k in ("hw_flop_frac", "lanes_active", "l2_hit_rate", "l1_hit_rate"):
+                if k in pmc_pending:
+                    r[k] = pmc_pending[k]
+            if "note" in pmc_pending:
+                r["pmc_note"] = pmc_pending["note"]
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: the other ranks would wait at the barrier
             out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
     if world > 1:

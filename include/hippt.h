@@ -126,6 +126,8 @@ typedef struct hippt_scene {
                                         listed more than once (several ranks share it: a one-GPU box can rehearse the
                                         split, the per-rank contexts / threads / streams and the sum) */
 
+#define HIPPT_FLAG_TRAVERSAL_STATS 256u /* LBVH queue pipeline: count what its rays fetch (hippt_read_traversal_stats) */
+
 typedef struct hippt_options {
     uint32_t sample_begin; /* first global sample index rendered by this call */
     uint32_t sample_count; /* 0 = scene.samples - sample_begin                */
@@ -245,6 +247,13 @@ int hippt_resolve_device(hippt_context *ctx, const float *d_accum, uint32_t spp,
 /* Waits for the context's stream and copies out the event counters
  * accumulated since the last call (then zeroes them). */
 int hippt_read_counters(hippt_context *ctx, uint64_t *counters);
+
+/* LBVH queue pipeline launched with HIPPT_FLAG_TRAVERSAL_STATS: what its traversal kernels fetched since the last
+ * call (then zeroed): stats10 = {rays, nodes visited (32 B each), leaf fetches (two spheres = 32 B each), aux rows
+ * (16 B each)} of the closest-hit traversals, then the same four of the shadow-ray traversals, then how many of the
+ * node visits of either kind were served from the LDS copy of the tree's first levels. No reference analogue
+ * (the reference's closest hit is a loop over all objects, src/renderer.rs:356-362): measurement only. */
+int hippt_read_traversal_stats(hippt_context *ctx, uint64_t *stats10);
 
 /* Average duration in ms of the trace-kernel launches issued through this
  * context since the last call (HIP events on the launch stream), and their

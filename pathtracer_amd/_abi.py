@@ -18,6 +18,7 @@ FLAG_TABLES_GLOBAL = 16
 FLAG_MEGAKERNEL = 32
 FLAG_NO_SLICES = 64
 FLAG_LOCAL_REDUCE = 128
+FLAG_TRAVERSAL_STATS = 256
 
 COUNTER_NAMES = (
     "paths", "extend_rays", "extend_hits", "shadow_rays", "shadow_sphere_tests",
@@ -83,7 +84,7 @@ EXPORTED_SYMBOLS = (
     "hippt_test_tonemap", "hippt_test_rng",
     "hippt_render_accum_add_f32", "hippt_resolve_f32", "hippt_checkpoint_save", "hippt_checkpoint_load",
     "hippt_render_rgba8_multi", "hippt_render_accum_f32_multi", "hippt_sample_range", "hippt_device_count",
-    "hippt_scene_dump", "hippt_test_shadow_nee", "hippt_render_accum_device_noalloc",
+    "hippt_scene_dump", "hippt_test_shadow_nee", "hippt_render_accum_device_noalloc", "hippt_read_traversal_stats",
 )
 
 _lib = None
@@ -146,6 +147,7 @@ def load_library():
     lib.hippt_render_accum_device_noalloc.argtypes = [C.c_void_p, C.POINTER(Options), C.c_void_p, C.c_void_p]
     lib.hippt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     lib.hippt_read_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.hippt_read_traversal_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.hippt_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     lib.hippt_render_rgba8.argtypes = [C.POINTER(SceneC), C.POINTER(Options), C.c_void_p]
     lib.hippt_render_accum_f32.argtypes = [C.POINTER(SceneC), C.POINTER(Options), C.c_void_p, C.c_void_p]

@@ -236,7 +236,7 @@ int build_bvh(const float4 *d_blob, const pt::Params &P, pt::BvhBuffers &out, hi
     return HIPPT_OK;
 }
 pt::Bvh bvh_view(const pt::BvhBuffers &b) {
-    return pt::Bvh{b.nodes, b.sph_sorted, b.aux_sorted, b.n, {b.grid_lo[0], b.grid_lo[1], b.grid_lo[2]},
+    return pt::Bvh{b.nodes, b.top, b.sph_sorted, b.aux_sorted, b.n, {b.grid_lo[0], b.grid_lo[1], b.grid_lo[2]},
                    {b.grid_cell[0], b.grid_cell[1], b.grid_cell[2]}};
 }
 }  // namespace
@@ -248,7 +248,7 @@ struct hippt_context {
     bool has_scene = false;
     float4 *d_blob = nullptr;
     size_t d_blob_cap = 0;
-    unsigned long long *d_counters = nullptr;
+    unsigned long long *d_counters = nullptr;  // HIPPT_N_COUNTERS event counters + 10 traversal statistics
     uint32_t samples = 0;
     void *wf_ws = nullptr;  // wavefront path-state workspace (allocated on first use)
     size_t wf_ws_bytes = 0;
@@ -278,8 +278,8 @@ int hippt_create(int device, hippt_context **out_ctx) {
     hippt_context *ctx = new hippt_context();
     ctx->device = device;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_counters, HIPPT_N_COUNTERS * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, HIPPT_N_COUNTERS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_counters, (HIPPT_N_COUNTERS + 10) * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, (HIPPT_N_COUNTERS + 10) * sizeof(unsigned long long));
     if (e != hipSuccess) {
         hippt_destroy(ctx);
         return hippt_set_error(HIPPT_ERR_DEVICE, "context setup failed: %s", hipGetErrorString(e));
@@ -387,7 +387,11 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
         if ((!use_bvh && !lds) || count || P.n_mat > 0xffffu || P.max_depth > 31u)
             return hippt_set_error(HIPPT_ERR_INVALID, "the wavefront variants support LDS-sized scenes or LBVH scenes, no counters, "
                                                       "<= 65535 materials and max_depth <= 31");
-        size_t need = use_bvh ? pt::wfb_workspace_bytes((uint32_t)pixels, P.n_light) : pt::wf_workspace_bytes((uint32_t)pixels);
+        // LBVH pipeline: several sample streams per pixel (pt_wavefront_bvh.hip), sized for the largest chunk of this call
+        const uint64_t per_chunk = std::max<uint64_t>(1, kPathsPerLaunch / pixels);
+        if (use_bvh && !(o.flags & HIPPT_FLAG_NO_SLICES))
+            P.wf_streams_log2 = pt::wfb_streams_log2((uint32_t)pixels, (uint32_t)std::min<uint64_t>(cnt, per_chunk), P.n_light);
+        size_t need = use_bvh ? pt::wfb_workspace_bytes((uint32_t)pixels << P.wf_streams_log2, P.n_light) : pt::wf_workspace_bytes((uint32_t)pixels);
         if (need > ctx->wf_ws_bytes) {
             HIP_TRY(hipStreamSynchronize(st));
             if (ctx->wf_ws) HIP_TRY(hipFree(ctx->wf_ws));
@@ -395,6 +399,15 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
             ctx->wf_ws_bytes = 0;
             HIP_TRY(hipMalloc(&ctx->wf_ws, need));
             ctx->wf_ws_bytes = need;
+        }
+        const size_t need_slices = P.wf_streams_log2 ? ((size_t)pixels * 3 * sizeof(float)) << P.wf_streams_log2 : 0;
+        if (need_slices > ctx->slice_bytes) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (ctx->slice_buf) HIP_TRY(hipFree(ctx->slice_buf));
+            ctx->slice_buf = nullptr;
+            ctx->slice_bytes = 0;
+            HIP_TRY(hipMalloc((void **)&ctx->slice_buf, need_slices));
+            ctx->slice_bytes = need_slices;
         }
     }
     uint64_t per = kPathsPerLaunch / pixels;
@@ -413,8 +426,13 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
         auto &ev = ctx->ev_pool[ctx->ev_used++];
         HIP_TRY(hipEventRecord(ev.first, st));
         const uint32_t stack_entries = (uint32_t)std::min(pt::BVH_STACK, std::max(8, ctx->bvh_depth + 2));
-        if (wavefront && use_bvh)
-            HIP_TRY(pt::wavefront_bvh_render(P, ctx->d_blob, bvh_view(ctx->bvh), stack_entries, d_accum, ctx->wf_ws, st, nullptr));
+        if (wavefront && use_bvh) {
+            pt::Params Pc = P;  // a short last chunk may have fewer samples than streams
+            Pc.wf_streams_log2 = std::min(P.wf_streams_log2, pt::wfb_streams_log2((uint32_t)pixels, c, P.n_light));
+            HIP_TRY(pt::wavefront_bvh_render(Pc, ctx->d_blob, bvh_view(ctx->bvh), stack_entries, d_accum, ctx->wf_ws, st, nullptr,
+                                             (o.flags & HIPPT_FLAG_TRAVERSAL_STATS) ? ctx->d_counters + HIPPT_N_COUNTERS : nullptr,
+                                             ctx->slice_buf));
+        }
         else if (wavefront)
             HIP_TRY(pt::wavefront_render(P, ctx->d_blob, d_accum, ctx->wf_ws, st, nullptr));
         else if (use_bvh)
@@ -548,6 +566,15 @@ int hippt_read_counters(hippt_context *ctx, uint64_t *counters) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(counters, ctx->d_counters, HIPPT_N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(ctx->d_counters, 0, HIPPT_N_COUNTERS * sizeof(uint64_t)));
+    return HIPPT_OK;
+}
+
+int hippt_read_traversal_stats(hippt_context *ctx, uint64_t *stats10) {
+    if (!ctx || !stats10) return hippt_set_error(HIPPT_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(stats10, ctx->d_counters + HIPPT_N_COUNTERS, 10 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(ctx->d_counters + HIPPT_N_COUNTERS, 0, 10 * sizeof(uint64_t)));
     return HIPPT_OK;
 }
 

@@ -18,47 +18,73 @@ namespace pt {
 // one access per lane and 16-byte load), so two loads per node instead of four is what matters.
 // child >= 0: internal node index; child < 0: leaf ~child = position in the
 // Morton-sorted sphere arrays.
+// The first kBvhTopLevels levels of the tree are ALSO kept as a complete binary heap (slot 0 = root, children of
+// slot e at 2e+1 / 2e+2, unused slots zero) so that the queue pipeline's traversal kernels can hold them in LDS: a
+// child pointer with kBvhTopFlag set is a heap slot, any other pointer is a node of `nodes` (>= 0) or a leaf (< 0) as
+// before. Every lane of a traversal wave chases its own pointer, and 16-byte gathers cost the vector L1 about one
+// lane per clock and CU (tools/gather_microbench.hip: 0.43 lane-loads per clock per CU from a 3 MB table, 4.7 from
+// LDS). Measured on C4: 6 levels (63 nodes, 2 KB of LDS, 19 % of the node visits) +2.7 %; 8-10 levels
+// serve 28-38 % of the visits but their 8-32 KB cost resident waves, and the net is -3...-8 %.
+#ifndef PT_BVH_TOP_LEVELS
+#define PT_BVH_TOP_LEVELS 6
+#endif
+constexpr int kBvhTopLevels = PT_BVH_TOP_LEVELS;
+constexpr int kBvhTopSlots = (1 << kBvhTopLevels) - 1;  // 63 nodes, 2 016 bytes
+constexpr int kBvhTopFlag = 1 << 30;
+
 struct Bvh {
     const uint4 *__restrict__ nodes;
+    const uint4 *__restrict__ top;   // kBvhTopSlots x 2 uint4
     const float4 *__restrict__ sph;  // sorted {c, r*r}
     const float4 *__restrict__ aux;  // sorted {1/r, material, scene order, 0}
     uint32_t n;                      // number of spheres (>= 2)
     float g_lo[3], g_cell[3];        // box coordinate = g_lo + q * g_cell
 };
 
+// Child boxes stay in GRID units (the 16-bit integers as floats); the ray is brought into grid units once, when it
+// starts its traversal: world = g_lo + q * cell, so the slab distance (world - ro) / rd is
+//     t(q) = q * (cell / rd) + (g_lo - ro) / rd = fma(q, slope, off),
+// one fma per box face with per-ray slope / off instead of decode-fma + subtract + multiply per face (the traversal
+// kernels are bound by instruction issue: 130 VALU instructions per node visit at 50 % lane occupancy).
+// Rounding: t(q) is off by <= ~2e-7 (65536 + |ro - g_lo| / cell) grid steps, far below the outward margin of the
+// boxes (>= 2 steps, pt_bvh_build.hip), so a box still never rejects a hit its sphere test accepts.
 struct NodeBoxes {
-    F3 llo, lhi, rlo, rhi;
+    F3 llo, lhi, rlo, rhi;  // grid units
     int left, right;
 };
-__device__ __forceinline__ NodeBoxes load_node(const Bvh &B, int node) {
-    uint4 a = B.nodes[node * 2 + 0], b = B.nodes[node * 2 + 1];
+__device__ __forceinline__ NodeBoxes decode_node(uint4 a, uint4 b) {
     auto lo16 = [](uint32_t v) { return (float)(v & 0xffffu); };
     auto hi16 = [](uint32_t v) { return (float)(v >> 16); };
     NodeBoxes nb;
-    nb.llo = F3{fmaf(lo16(a.x), B.g_cell[0], B.g_lo[0]), fmaf(hi16(a.x), B.g_cell[1], B.g_lo[1]), fmaf(lo16(a.y), B.g_cell[2], B.g_lo[2])};
-    nb.lhi = F3{fmaf(hi16(a.y), B.g_cell[0], B.g_lo[0]), fmaf(lo16(a.z), B.g_cell[1], B.g_lo[1]), fmaf(hi16(a.z), B.g_cell[2], B.g_lo[2])};
-    nb.rlo = F3{fmaf(lo16(b.x), B.g_cell[0], B.g_lo[0]), fmaf(hi16(b.x), B.g_cell[1], B.g_lo[1]), fmaf(lo16(b.y), B.g_cell[2], B.g_lo[2])};
-    nb.rhi = F3{fmaf(hi16(b.y), B.g_cell[0], B.g_lo[0]), fmaf(lo16(b.z), B.g_cell[1], B.g_lo[1]), fmaf(hi16(b.z), B.g_cell[2], B.g_lo[2])};
+    nb.llo = F3{lo16(a.x), hi16(a.x), lo16(a.y)};
+    nb.lhi = F3{hi16(a.y), lo16(a.z), hi16(a.z)};
+    nb.rlo = F3{lo16(b.x), hi16(b.x), lo16(b.y)};
+    nb.rhi = F3{hi16(b.y), lo16(b.z), hi16(b.z)};
     nb.left = (int)a.w;
     nb.right = (int)b.w;
     return nb;
+}
+__device__ __forceinline__ NodeBoxes load_node(const Bvh &B, int node) {
+    return decode_node(B.nodes[node * 2 + 0], B.nodes[node * 2 + 1]);
 }
 
 
 constexpr int BVH_STACK = 48;  // entries per lane (LDS); deeper trees raise an error at build time
 
 struct BoxRay {
-    F3 ro, inv;
+    F3 slope, off;  // t(q) = fma(q, slope, off) per axis
 };
-__device__ __forceinline__ BoxRay make_box_ray(F3 ro, F3 rd) {
+__device__ __forceinline__ BoxRay make_box_ray(const Bvh &B, F3 ro, F3 rd) {
     auto safe = [](float d) { return fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d; };
-    return BoxRay{ro, F3{rcp(safe(rd.x)), rcp(safe(rd.y)), rcp(safe(rd.z))}};
+    const F3 inv = F3{rcp(safe(rd.x)), rcp(safe(rd.y)), rcp(safe(rd.z))};
+    return BoxRay{F3{B.g_cell[0] * inv.x, B.g_cell[1] * inv.y, B.g_cell[2] * inv.z},
+                  F3{(B.g_lo[0] - ro.x) * inv.x, (B.g_lo[1] - ro.y) * inv.y, (B.g_lo[2] - ro.z) * inv.z}};
 }
-// Entry distance of the ray into the box, +inf if it misses or lies beyond t_max / behind the origin.
+// Entry distance of the ray into the box (grid units), +inf if it misses or lies beyond t_max / behind the origin.
 __device__ __forceinline__ float box_entry(const BoxRay &b, F3 lo, F3 hi, float t_max) {
-    float x0 = (lo.x - b.ro.x) * b.inv.x, x1 = (hi.x - b.ro.x) * b.inv.x;
-    float y0 = (lo.y - b.ro.y) * b.inv.y, y1 = (hi.y - b.ro.y) * b.inv.y;
-    float z0 = (lo.z - b.ro.z) * b.inv.z, z1 = (hi.z - b.ro.z) * b.inv.z;
+    float x0 = fmaf(lo.x, b.slope.x, b.off.x), x1 = fmaf(hi.x, b.slope.x, b.off.x);
+    float y0 = fmaf(lo.y, b.slope.y, b.off.y), y1 = fmaf(hi.y, b.slope.y, b.off.y);
+    float z0 = fmaf(lo.z, b.slope.z, b.off.z), z1 = fmaf(hi.z, b.slope.z, b.off.z);
     float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
     float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_max));
     return tmin <= tmax ? tmin : __builtin_inff();
@@ -68,7 +94,7 @@ __device__ __forceinline__ float box_entry(const BoxRay &b, F3 lo, F3 hi, float 
 // stack: this lane's LDS column, element k at stack[k * stride].
 __device__ __forceinline__ void bvh_closest(const Bvh &B, const RayK &r, float &best_t, int &best_leaf,
                                             uint32_t &best_ord, uint32_t *stack, uint32_t stride, uint32_t &n_tests) {
-    BoxRay br = make_box_ray(r.ro, r.rd);
+    BoxRay br = make_box_ray(B, r.ro, r.rd);
     auto leaf = [&](int lf, float4 sph) {
         float t = sphere_t(r, sph);
         ++n_tests;
@@ -116,7 +142,7 @@ __device__ __forceinline__ void bvh_closest(const Bvh &B, const RayK &r, float &
 // Any sphere with t > 0 and t*t < lim (renderer.rs:46).
 __device__ __forceinline__ bool bvh_any(const Bvh &B, const RayK &r, float lim, uint32_t *stack, uint32_t stride,
                                         uint32_t &n_tests) {
-    BoxRay br = make_box_ray(r.ro, r.rd);
+    BoxRay br = make_box_ray(B, r.ro, r.rd);
     float t_max = fsqrt(lim) * 1.000001f;
     bool occ = false;
     int node = 0, sp = 0;

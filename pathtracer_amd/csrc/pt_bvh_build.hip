@@ -15,6 +15,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "pt_bvh_build.h"
+#include "pt_bvh.h"
 
 namespace pt {
 namespace {
@@ -207,6 +208,43 @@ struct Tmp {
         if (e_ != hipSuccess) return e_; \
     } while (0)
 
+// Heap copy of the first kBvhTopLevels levels (pt_bvh.h). One block; level by level.
+__global__ __launch_bounds__(1024) void k_top(const uint4 *__restrict__ nodes, uint4 *__restrict__ top) {
+    __shared__ int src[kBvhTopSlots];  // node of `nodes` behind each heap slot, -1: none
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) src[0] = 0;
+    __syncthreads();
+    for (int level = 0; level < kBvhTopLevels; ++level) {
+        const int base = (1 << level) - 1, cnt = 1 << level;
+        if (tid < cnt) {
+            const int e = base + tid, g = src[e];
+            uint4 a = uint4{0, 0, 0, 0}, b = uint4{0, 0, 0, 0};
+            int l = -1, r = -1;
+            if (g >= 0) {
+                a = nodes[g * 2 + 0];
+                b = nodes[g * 2 + 1];
+                if (level + 1 < kBvhTopLevels) {  // internal children move into the heap as well
+                    if ((int)a.w >= 0) {
+                        l = (int)a.w;
+                        a.w = (uint32_t)(kBvhTopFlag | (2 * e + 1));
+                    }
+                    if ((int)b.w >= 0) {
+                        r = (int)b.w;
+                        b.w = (uint32_t)(kBvhTopFlag | (2 * e + 2));
+                    }
+                }
+            }
+            if (level + 1 < kBvhTopLevels) {
+                src[2 * e + 1] = l;
+                src[2 * e + 2] = r;
+            }
+            top[e * 2 + 0] = a;
+            top[e * 2 + 1] = b;
+        }
+        __syncthreads();
+    }
+}
+
 hipError_t bvh_build(const float4 *d_sph, const float4 *d_aux, uint32_t n, BvhBuffers &out, hipStream_t st, int *depth_out) {
     if (n < 2) return hipErrorInvalidValue;
     const int N = (int)n, n_nodes = 2 * N - 1;
@@ -225,6 +263,7 @@ hipError_t bvh_build(const float4 *d_sph, const float4 *d_aux, uint32_t n, BvhBu
     BVH_TRY(hipMalloc(&ready_b.p, (size_t)n_nodes * 4));
     BVH_TRY(hipMalloc(&done.p, 4));
     BVH_TRY(hipMalloc((void **)&out.nodes, (size_t)(N - 1) * 32));
+    BVH_TRY(hipMalloc((void **)&out.top, (size_t)kBvhTopSlots * 32));
     BVH_TRY(hipMalloc((void **)&out.sph_sorted, (size_t)n * 16));
     BVH_TRY(hipMalloc((void **)&out.aux_sorted, (size_t)n * 16));
     out.n = n;
@@ -283,13 +322,14 @@ hipError_t bvh_build(const float4 *d_sph, const float4 *d_aux, uint32_t n, BvhBu
     if (!std::isfinite(max_abs) || !std::isfinite(min_cell)) return hipErrorInvalidValue;
     // f32 rounding of (v - g) * inv at build time and of g + q * cell at traversal time: a few ulps of the largest
     // coordinate, expressed in grid steps, plus one
-    G.margin = 1 + (int)std::min(200.0, std::ceil(8.0 * max_abs * 1.2e-7 / min_cell));
+    G.margin = 2 + (int)std::min(200.0, std::ceil(8.0 * max_abs * 1.2e-7 / min_cell));  // + 1 step for the ray-side rounding of t(q) = fma(q, slope, off), pt_bvh.h
     for (int k = 0; k < 3; ++k) {
         out.grid_lo[k] = G.lo[k];
         out.grid_cell[k] = G.cell[k];
     }
     hipLaunchKernelGGL(k_pack, dim3(g), dim3(bs), 0, st, N, (const int *)left.p, (const int *)right.p, (const float4 *)lo.p,
                        (const float4 *)hi.p, G, out.nodes);
+    hipLaunchKernelGGL(k_top, dim3(1), dim3(1024), 0, st, (const uint4 *)out.nodes, out.top);
     BVH_TRY(hipStreamSynchronize(st));
     BVH_TRY(hipGetLastError());
     if (depth_out) *depth_out = depth;
@@ -298,6 +338,7 @@ hipError_t bvh_build(const float4 *d_sph, const float4 *d_aux, uint32_t n, BvhBu
 
 void bvh_free(BvhBuffers &b) {
     if (b.nodes) (void)hipFree(b.nodes);
+    if (b.top) (void)hipFree(b.top);
     if (b.sph_sorted) (void)hipFree(b.sph_sorted);
     if (b.aux_sorted) (void)hipFree(b.aux_sorted);
     b = BvhBuffers{};

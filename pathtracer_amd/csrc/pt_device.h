@@ -35,6 +35,7 @@ struct Params {
     uint32_t blob_f4;             // blob size in float4
     uint32_t sample_begin, sample_count, max_depth, seed;
     uint32_t tiles_x;             // 16x16 pixel tiles per row
+    uint32_t wf_streams_log2;     // LBVH queue pipeline: every pixel's samples run as 2^this concurrent streams (pt_wavefront_bvh.hip)
 };
 
 // ---- float3 -------------------------------------------------------------------

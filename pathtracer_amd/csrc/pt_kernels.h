@@ -22,8 +22,14 @@ hipError_t launch_unit_intersect_bvh(const Params &P, const float4 *blob, const 
 size_t wf_workspace_bytes(uint32_t n_pixels);
 // queue pipeline with persistent LBVH traversal kernels for many-sphere scenes (pt_wavefront_bvh.hip)
 size_t wfb_workspace_bytes(uint32_t n_pixels, uint32_t n_light);
+// stats (optional, device, 8 x u64): {rays, nodes, leaf fetches, aux rows} of the closest-hit and of the any-hit traversals
 hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &bvh, uint32_t stack_entries, float *accum,
-                                void *workspace, hipStream_t st, uint32_t *iterations_out);
+                                void *workspace, hipStream_t st, uint32_t *iterations_out, unsigned long long *stats = nullptr,
+                                float *partial = nullptr);
+// sample streams per pixel (log2) for a launch of sample_count samples over n_pixels pixels: ~32 M paths in flight
+uint32_t wfb_streams_log2(uint32_t n_pixels, uint32_t sample_count, uint32_t n_light);
+// accum[i] += slice 0 + slice 1 + ... (fixed order) of `partial` (slices x n floats)
+hipError_t launch_add_slices(float *accum, const float *partial, uint32_t slices, size_t n, hipStream_t st);
 hipError_t wavefront_render(const Params &P, const float4 *blob, float *accum, void *workspace, hipStream_t st,
                             uint32_t *iterations_out);
 // dst[i] += src[i] (sum of per-rank accumulators on one device)

@@ -552,6 +552,10 @@ hipError_t launch_megakernel_bvh(const Params &P, const float4 *blob, const Bvh 
     return hipGetLastError();
 }
 
+hipError_t launch_add_slices(float *accum, const float *partial, uint32_t slices, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(pt_add_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, accum, partial, slices, n);
+    return hipGetLastError();
+}
 hipError_t launch_add(float *dst, const float *src, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(pt_add_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, src, 1u, n);
     return hipGetLastError();

@@ -19,6 +19,15 @@
 //   wfb_shade           : plane occlusion, BRDF evaluation (renderer.rs:49-82), Russian roulette, lobe
 //                         sampling (renderer.rs:323-349) or phase-function scatter (:269-286)
 //
+// SAMPLE STREAMS. A queue entry is a (pixel, stream) pair: the samples of a launch are cut into 2^k contiguous parts
+// per pixel (P.wf_streams_log2, chosen by the host so that ~16 M paths are in flight) and every part is a stream with
+// its own entry, its own running sum and its own slice of a partial-sum buffer, added up in a fixed order at the end.
+// Why: a round is five dependent launches, and each traversal launch lasts at least as long as its LONGEST ray — a
+// ray that skims the sphere slab visits several hundred nodes at ~1 us per dependent visit, as long as the other two
+// million rays of a 1080p round take together. Measured with one stream per pixel: 160 / 364 / 495 / 562 Mpaths/s at
+// 0.5 / 2 / 8 / 33 M pixels, i.e. 43 % of a 1080p round was that fixed cost. More paths per round amortise it, and
+// there are 2^k times fewer rounds.
+//
 // The arithmetic is the device code of the megakernels (pt_device.h, pt_bvh.h) with the same RNG stream
 // per (pixel, sample) and the same draw order, so the image equals the BVH megakernel's.
 #include "pt_kernels.h"
@@ -38,9 +47,29 @@ namespace {
 constexpr uint32_t kFetchChunk = 256;          // rays a wave reserves with one atomic
 constexpr uint32_t kFetchMin = WFB_FETCH_MIN;  // idle lanes that trigger a refill
 
+// Entry id v = pixel << k | stream. Stream j of 2^k renders the j-th part of the launch's samples (parts differ by at
+// most one sample; the host keeps 2^k <= sample_count, so no part is empty).
+__device__ __forceinline__ void stream_range(const Params &P, uint32_t v, uint32_t &begin, uint32_t &end) {
+    const uint32_t k = 1u << P.wf_streams_log2, j = v & (k - 1u);
+    const uint32_t q = P.sample_count >> P.wf_streams_log2, r = P.sample_count & (k - 1u);
+    begin = P.sample_begin + j * q + min(j, r);
+    end = begin + q + (j < r ? 1u : 0u);
+}
+// where a finished stream leaves its sum: its slice of the partial-sum buffer (= accum itself with one stream)
+__device__ __forceinline__ void stream_store(const Params &P, float *__restrict__ out, uint32_t v, F3 sum) {
+    const uint32_t pix = v >> P.wf_streams_log2, j = v & ((1u << P.wf_streams_log2) - 1u);
+    float *o = out + ((size_t)j * P.width * P.height + pix) * 3;
+    if (P.wf_streams_log2 == 0u) {
+        o[0] += sum.x, o[1] += sum.y, o[2] += sum.z;
+    } else {
+        o[0] = sum.x, o[1] = sum.y, o[2] = sum.z;
+    }
+}
+
 // renderer.rs:170-178: the pixel's next camera path
-__device__ __forceinline__ void new_camera_path(const TblGlobal &tbl, const Params &P, uint32_t seed_mixed, uint32_t pix, uint32_t &next, Rng &rng,
+__device__ __forceinline__ void new_camera_path(const TblGlobal &tbl, const Params &P, uint32_t seed_mixed, uint32_t v, uint32_t &next, Rng &rng,
                                                 F3 &ro, F3 &rd, F3 &T, uint32_t &depth, int &media) {
+    const uint32_t pix = v >> P.wf_streams_log2;
     uint32_t px = pix % P.width, py = pix / P.width;
     rng.seed(seed_mixed, mix32(pix + seed_mixed), next);
     float jx = rng.gen(), jy = rng.gen(), ds = rng.gen(), dt = rng.gen();
@@ -66,13 +95,14 @@ __device__ __forceinline__ void push_ray(const WfQueue &Q, uint32_t pos, uint32_
 
 }  // namespace
 
-// Every pixel starts with the camera path of its first sample; entries of the ray queue are always live rays.
+// Every stream starts with the camera path of its first sample; entries of the ray queue are always live rays.
 __global__ __launch_bounds__(256) void wfb_init(Params P, const float4 *__restrict__ blob, WfQueue Q, uint32_t n) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     TblGlobal tbl{blob};
     const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
-    uint32_t next = P.sample_begin, depth;
+    uint32_t next, s_end, depth;
+    stream_range(P, i, next, s_end);
     int media;
     Rng rng{0u, 1u};
     F3 ro, rd, T;
@@ -85,15 +115,27 @@ __global__ __launch_bounds__(256) void wfb_init(Params P, const float4 *__restri
 // (same result as pt_bvh.h: bvh_closest); out: hit_t[i], hit_leaf[i] (-1: none). ANY = true: shadow ray r
 // is sample k of shade-queue entry e with ray_list[r] = k * cap + e (origin Q.F_X[e] + 1e-4 l, direction l
 // and tmax from the sample planes); out: occ[k * cap + e] (same result as bvh_any).
-template <bool ANY>
-__global__ __launch_bounds__(256) void wfb_traverse(Bvh bvh, WfQueue Q, const float *__restrict__ samples,
+// STATS: also counts what the rays fetch (stats[0..3] = rays, nodes visited (32 B each), leaf fetches (two spheres,
+// 32 B, each), aux rows (16 B)), wave-reduced, for the memory roofline of bench.py --config c4.
+#ifndef WFB_INFLIGHT_LOG2
+#define WFB_INFLIGHT_LOG2 25  // paths in flight the host aims for (sample streams per pixel); 2^24: -5 %, 2^26: +3 %
+#endif
+#ifndef WFB_TRAV_THREADS
+#define WFB_TRAV_THREADS 256
+#endif
+constexpr uint32_t kTravThreads = WFB_TRAV_THREADS;  // traversal blocks: one LDS copy of the tree's top per 8 waves
+template <bool ANY, bool STATS = false>
+__global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q, const float *__restrict__ samples,
                                                     const uint32_t *__restrict__ ray_list, const uint32_t *__restrict__ ray_count,
                                                     uint32_t *__restrict__ head,
                                                     float *__restrict__ hit_t, int *__restrict__ hit_leaf,
-                                                    uint8_t *__restrict__ occ_out) {
-    extern __shared__ uint32_t s_stack[];  // stack_entries x 256
-    uint32_t *stack = s_stack + threadIdx.x;
-    const uint32_t stride = 256u;
+                                                    uint8_t *__restrict__ occ_out, unsigned long long *__restrict__ stats = nullptr) {
+    uint32_t st_rays = 0, st_nodes = 0, st_leaves = 0, st_aux = 0, st_top = 0;
+    extern __shared__ uint4 s_top[];  // the tree's first levels (kBvhTopSlots x 2 uint4), then stack_entries x kTravThreads words
+    for (uint32_t i = threadIdx.x; i < 2u * kBvhTopSlots; i += kTravThreads) s_top[i] = bvh.top[i];
+    __syncthreads();
+    uint32_t *stack = reinterpret_cast<uint32_t *>(s_top + 2 * kBvhTopSlots) + threadIdx.x;
+    const uint32_t stride = kTravThreads;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_rays = ANY ? *ray_count : *Q.count;
     const size_t cap = Q.cap;
@@ -147,10 +189,11 @@ __global__ __launch_bounds__(256) void wfb_traverse(Bvh bvh, WfQueue Q, const fl
                         best_ord = 0xffffffffu;
                         out_idx = ridx;
                     }
-                    br = make_box_ray(r.ro, r.rd);
-                    node = 0;
+                    br = make_box_ray(bvh, r.ro, r.rd);
+                    node = kBvhTopFlag;  // the root, in LDS
                     sp = 0;
                     has = true;
+                    if (STATS) ++st_rays;
                 }
                 w_next += min(n_idle, avail);
             } else if (n_idle == 64u) {
@@ -160,7 +203,16 @@ __global__ __launch_bounds__(256) void wfb_traverse(Bvh bvh, WfQueue Q, const fl
         if (!has) continue;
 
         // ---- one node (pt_bvh.h: bvh_closest / bvh_any loop body) ----
-        NodeBoxes nb = load_node(bvh, node);
+        uint4 na, nb4;
+        if (node & kBvhTopFlag) {
+            const int slot = node & (kBvhTopFlag - 1);
+            na = s_top[slot * 2 + 0], nb4 = s_top[slot * 2 + 1];
+            if (STATS) ++st_top;
+        } else {
+            na = bvh.nodes[node * 2 + 0], nb4 = bvh.nodes[node * 2 + 1];
+        }
+        NodeBoxes nb = decode_node(na, nb4);
+        if (STATS) ++st_nodes;
         int left = nb.left, right = nb.right;
         const float bound = ANY ? t_max : best_t;
         float tl = box_entry(br, nb.llo, nb.lhi, bound);
@@ -173,6 +225,7 @@ __global__ __launch_bounds__(256) void wfb_traverse(Bvh bvh, WfQueue Q, const fl
             if (ll || rl) {  // both leaf spheres are fetched at once (one memory latency, not two); a lone leaf twice
                 const int il = ll ? ~left : ~right, ir = rl ? ~right : ~left;
                 const float4 sl = bvh.sph[il], sr = bvh.sph[ir];
+                if (STATS) ++st_leaves;
                 const float t0 = sphere_t(r, sl), t1 = sphere_t(r, sr);
                 occ = ((t0 > 0.0f) & (t0 * t0 < lim)) | ((t1 > 0.0f) & (t1 * t1 < lim));
                 if (ll) hl = false;
@@ -187,6 +240,7 @@ __global__ __launch_bounds__(256) void wfb_traverse(Bvh bvh, WfQueue Q, const fl
                 float t = sphere_t(r, sph);
                 if (t > 0.0f && t <= best_t) {
                     uint32_t ord = __float_as_uint(bvh.aux[lf].z);
+                    if (STATS) ++st_aux;
                     if (t < best_t || ord < best_ord) {  // renderer.rs:359-361: first minimum in scene order
                         best_t = t;
                         best = lf;
@@ -198,6 +252,7 @@ __global__ __launch_bounds__(256) void wfb_traverse(Bvh bvh, WfQueue Q, const fl
             if (ll || rl) {  // both leaf spheres are fetched at once (one memory latency, not two)
                 const int il = ll ? ~left : ~right, ir = rl ? ~right : ~left;
                 const float4 sl = bvh.sph[il], sr = bvh.sph[ir];
+                if (STATS) ++st_leaves;
                 leaf(il, sl);
                 if (ll && rl) leaf(ir, sr);
                 if (ll) hl = false;
@@ -227,6 +282,14 @@ __global__ __launch_bounds__(256) void wfb_traverse(Bvh bvh, WfQueue Q, const fl
         }
         if (finished) has = false;
     }
+    if (STATS) {
+        uint32_t v[5] = {st_rays, st_nodes, st_leaves, st_aux, st_top};
+        for (int k = 0; k < 5; ++k) {
+            unsigned long long w = v[k];
+            for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off);
+            if (lane == 0 && w) atomicAdd(&stats[k < 4 ? (ANY ? 4 : 0) + k : (ANY ? 9 : 8)], w);
+        }
+    }
 }
 
 // Everything of one path vertex that follows the closest-sphere query and precedes next-event estimation.
@@ -237,7 +300,6 @@ __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restr
     TblGlobal tbl{blob};
     Tracer<TblGlobal, false, true> tr(P, tbl, bvh, nullptr);
     const uint32_t count = *Qin.count;
-    const uint32_t s_end = P.sample_begin + P.sample_count;
     const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
     for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
         uint32_t qi = base + threadIdx.x;
@@ -308,16 +370,14 @@ __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restr
                 }
             }
             if (!to_shade) {
-                if (!alive && next < s_end) {  // the pixel's next sample takes the finished path's place
+                uint32_t s_begin, s_end;
+                stream_range(P, pix, s_begin, s_end);
+                if (!alive && next < s_end) {  // the stream's next sample takes the finished path's place
                     new_camera_path(tbl, P, seed_mixed, pix, next, rng, ro, rd, T, depth, media);
                     alive = true;
                 }
                 to_next = alive;
-                if (!to_next) {  // pixel done: its sum goes to the accumulator
-                    accum[3 * (size_t)pix + 0] += sum.x;
-                    accum[3 * (size_t)pix + 1] += sum.y;
-                    accum[3 * (size_t)pix + 2] += sum.z;
-                }
+                if (!to_next) stream_store(P, accum, pix, sum);  // stream done: its sum goes to its slice
             }
         }
         uint32_t pn, ps;
@@ -426,7 +486,6 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
     TblGlobal tbl{blob};
     const uint32_t count = *Qshade.count;
     const size_t cap = Qshade.cap;
-    const uint32_t s_end = P.sample_begin + P.sample_count;
     const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
     for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
         uint32_t qi = base + threadIdx.x;
@@ -523,22 +582,22 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
             }
             ++depth;
             if (depth >= P.max_depth) alive = false;
+            uint32_t s_begin, s_end;
+            stream_range(P, pix, s_begin, s_end);
             if (!alive && next < s_end) {
                 new_camera_path(tbl, P, seed_mixed, pix, next, rng, ro, rd, T, depth, media);
                 alive = true;
             }
             to_next = alive;
-            if (!to_next) {
-                accum[3 * (size_t)pix + 0] += sum.x;
-                accum[3 * (size_t)pix + 1] += sum.y;
-                accum[3 * (size_t)pix + 2] += sum.z;
-            }
+            if (!to_next) stream_store(P, accum, pix, sum);
         }
         uint32_t pn, unused;
         queue_reserve2(to_next, Qnext.count, pn, false, nullptr, unused, s_cnt, s_base);
         if (to_next) push_ray(Qnext, pn, pix, depth, media, next, sum, ro, rd, T, rng);
     }
 }
+
+#define WFB_TRAV wfb_traverse
 
 // ---- host driver -----------------------------------------------------------------------
 namespace {
@@ -560,9 +619,20 @@ WfbLayout wfb_layout(uint32_t n, uint32_t n_light) {
 
 size_t wfb_workspace_bytes(uint32_t n_pixels, uint32_t n_light) { return wfb_layout(n_pixels, n_light).total; }
 
+uint32_t wfb_streams_log2(uint32_t n_pixels, uint32_t sample_count, uint32_t n_light) {
+    uint32_t lg = 0;
+    while (lg < 6u && ((uint64_t)n_pixels << (lg + 1)) <= (1ull << WFB_INFLIGHT_LOG2) && (2u << lg) <= sample_count &&
+           wfb_layout(n_pixels << (lg + 1), n_light).total <= (16ull << 30))  // queues of at most 16 GiB
+        ++lg;
+    return lg;
+}
+
+// P.wf_streams_log2 streams per pixel; `partial` = 2^that slices of width*height*3 floats (unused with one stream).
 hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &bvh, uint32_t stack_entries, float *accum,
-                                void *workspace, hipStream_t st, uint32_t *iterations_out) {
-    const uint32_t n = P.width * P.height;
+                                void *workspace, hipStream_t st, uint32_t *iterations_out, unsigned long long *stats, float *partial) {
+    const uint32_t n = (P.width * P.height) << P.wf_streams_log2;
+    float *const sums = P.wf_streams_log2 ? partial : accum;
+    if (P.wf_streams_log2 && !partial) return hipErrorInvalidValue;
     const WfbLayout L = wfb_layout(n, P.n_light);
     uint8_t *w = (uint8_t *)workspace;
     uint32_t *counters = (uint32_t *)w;  // [0],[1]: ray queue counts (ping-pong), [2]: shade count, [3],[4]: fetch heads, [5]: shadow-ray count
@@ -586,27 +656,37 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
 
     const unsigned blocks_all = (n + 255) / 256;
     const unsigned grid = std::min(blocks_all, 256u * 8u);
-    const unsigned grid_trav = 256u * 8u;  // persistent: every CU full at 8 waves per SIMD
-    const size_t stack_bytes = (size_t)stack_entries * 256 * 4;
+    const unsigned grid_trav = 256u * 8u * 256u / kTravThreads;  // persistent: every CU full
+    const size_t stack_bytes = (size_t)kBvhTopSlots * 32 + (size_t)stack_entries * kTravThreads * 4;
     hipError_t e;
     if ((e = hipMemsetAsync(counters, 0, 4096, st)) != hipSuccess) return e;
     if (P.sample_count == 0) return hipSuccess;
     hipLaunchKernelGGL(wfb_init, dim3(blocks_all), dim3(256), 0, st, P, blob, Q[0], n);
-    const uint32_t max_iter = P.sample_count * P.max_depth + 1;
+    const uint32_t max_iter = ((P.sample_count >> P.wf_streams_log2) + 1u) * P.max_depth + 1;
     uint32_t it = 0;
     int cur = 0;
     for (; it < max_iter; ++it) {
         if ((e = hipMemsetAsync(&counters[1 - cur], 0, 4, st)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(&counters[2], 0, 16, st)) != hipSuccess) return e;  // shade count, both fetch heads, shadow-ray count
-        hipLaunchKernelGGL(wfb_traverse<false>, dim3(grid_trav), dim3(256), stack_bytes, st, bvh, Q[cur], (const float *)nullptr,
-                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, &counters[3], hit_t, hit_leaf, (uint8_t *)nullptr);
+        if (stats)
+            hipLaunchKernelGGL((WFB_TRAV<false, true>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, st, bvh, Q[cur], (const float *)nullptr,
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, &counters[3], hit_t, hit_leaf, (uint8_t *)nullptr, stats);
+        else
+            hipLaunchKernelGGL((WFB_TRAV<false, false>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, st, bvh, Q[cur], (const float *)nullptr,
+                               (const uint32_t *)nullptr, (const uint32_t *)nullptr, &counters[3], hit_t, hit_leaf, (uint8_t *)nullptr,
+                               (unsigned long long *)nullptr);
         hipLaunchKernelGGL(wfb_logic, dim3(grid), dim3(256), 0, st, P, blob, bvh, Q[cur], (const float *)hit_t,
-                           (const int *)hit_leaf, Q[1 - cur], Q[2], accum);
+                           (const int *)hit_leaf, Q[1 - cur], Q[2], sums);
         hipLaunchKernelGGL(wfb_nee_gen, dim3(grid), dim3(256), 0, st, P, blob, Q[2], samples, occ, ray_list, &counters[5]);
-        hipLaunchKernelGGL(wfb_traverse<true>, dim3(grid_trav), dim3(256), stack_bytes, st, bvh, Q[2], (const float *)samples,
-                           (const uint32_t *)ray_list, (const uint32_t *)&counters[5], &counters[4], (float *)nullptr, (int *)nullptr, occ);
+        if (stats)
+            hipLaunchKernelGGL((WFB_TRAV<true, true>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, st, bvh, Q[2], (const float *)samples,
+                               (const uint32_t *)ray_list, (const uint32_t *)&counters[5], &counters[4], (float *)nullptr, (int *)nullptr, occ, stats);
+        else
+            hipLaunchKernelGGL((WFB_TRAV<true, false>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, st, bvh, Q[2], (const float *)samples,
+                               (const uint32_t *)ray_list, (const uint32_t *)&counters[5], &counters[4], (float *)nullptr, (int *)nullptr, occ,
+                               (unsigned long long *)nullptr);
         hipLaunchKernelGGL(wfb_shade, dim3(grid), dim3(256), 0, st, P, blob, Q[2], (const float *)samples, (const uint8_t *)occ,
-                           Q[1 - cur], accum);
+                           Q[1 - cur], sums);
         cur = 1 - cur;
         if ((it & 15u) == 15u) {
             uint32_t left = 0;
@@ -619,6 +699,10 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
         }
     }
     if (iterations_out) *iterations_out = it;
+    if (P.wf_streams_log2) {
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = launch_add_slices(accum, partial, 1u << P.wf_streams_log2, (size_t)P.width * P.height * 3, st)) != hipSuccess) return e;
+    }
     return hipGetLastError();
 }
 

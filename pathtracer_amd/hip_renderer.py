@@ -144,6 +144,15 @@ class Context:
         _abi.check(self.lib.hippt_read_counters(self.h, cn), self.lib)
         return dict(zip(_abi.COUNTER_NAMES, [int(x) for x in cn]))
 
+    def read_traversal_stats(self):
+        """{closest, any} x {rays, nodes, leaf_fetches, aux_rows} of LBVH queue launches made with FLAG_TRAVERSAL_STATS."""
+        st = (C.c_uint64 * 10)()
+        _abi.check(self.lib.hippt_read_traversal_stats(self.h, st), self.lib)
+        names = ("rays", "nodes", "leaf_fetches", "aux_rows")
+        out = {"closest": dict(zip(names, [int(x) for x in st[:4]])), "any": dict(zip(names, [int(x) for x in st[4:8]]))}
+        out["closest"]["nodes_from_lds"], out["any"]["nodes_from_lds"] = int(st[8]), int(st[9])
+        return out
+
     def kernel_time_ms(self):
         tot, n = C.c_double(), C.c_uint32()
         _abi.check(self.lib.hippt_kernel_time_ms(self.h, C.byref(tot), C.byref(n)), self.lib)

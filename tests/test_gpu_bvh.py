@@ -145,3 +145,43 @@ def test_queue_pipeline_edge_cases(scene20k):
         hip_renderer.render_accum(s, flags=_abi.FLAG_WAVEFRONT | _abi.FLAG_MEGAKERNEL)
     with pytest.raises(_abi.HipptError):
         hip_renderer.render_accum(s, flags=_abi.FLAG_WAVEFRONT, max_depth=40)
+
+
+def test_c4_lbvh_equals_brute_force_on_the_first_2p20_camera_rays(hip):
+    """BASELINE config 4 / SURVEY §8d: LBVH vs brute-force closest hit on the first 2^20 camera rays (pixels in
+    row-major order, pixel centres, no lens offset) of the 100 000-sphere scene at 1920x1080: index, t and normal
+    must be EQUAL (the tree only prunes). Also the traversal statistics of the queue pipeline on that scene."""
+    from pathtracer_amd.synthetic import synthetic_spheres
+    s = synthetic_spheres(100000, 0x5EED, 1920, 1080, 256)
+    n_rays = 1 << 20
+    i = np.arange(n_rays)
+    xy = np.stack([i % s.width, i // s.width], 1)
+    u4 = np.tile(np.array([0.5, 0.5, 0.0, 0.0], np.float32), (n_rays, 1))
+    ro, rd = hip.camera_ray(s, xy, u4)
+    t_v, n_v, i_v = hip.intersect_bvh(s, ro, rd)
+    t_b, n_b, i_b = hip.intersect(s, ro, rd)
+    assert (i_b >= 1).mean() > 0.2 and (i_b < 0).mean() > 0.05        # the upper half of the image: spheres and sky
+    assert np.array_equal(i_b, i_v)
+    assert np.array_equal(t_b, t_v)
+    assert np.array_equal(n_b, n_v)
+
+
+def test_traversal_stats_of_the_queue_pipeline(scene20k):
+    import torch
+    from pathtracer_amd import _abi, hip_renderer
+    s = scene20k.with_render(128, 72, 4)
+    ctx = hip_renderer.Context(0)
+    ctx.set_scene(s)
+    acc = torch.zeros(s.width * s.height * 3, dtype=torch.float32, device="cuda")
+    ref = torch.zeros_like(acc)
+    ctx.render_accum_device(acc.data_ptr(), 0, 4, seed=3, flags=_abi.FLAG_TRAVERSAL_STATS)
+    ctx.render_accum_device(ref.data_ptr(), 0, 4, seed=3)
+    st = ctx.read_traversal_stats()
+    assert torch.equal(acc, ref)                                   # counting changes nothing
+    _, cn = hip_renderer.render_accum(s, seed=3, counters=True)     # BVH megakernel, event counters
+    assert st["closest"]["rays"] == cn["extend_rays"]
+    assert 0 < st["any"]["rays"] <= cn["shadow_rays"]             # samples that face away get no shadow ray
+    for k in ("closest", "any"):
+        assert st[k]["nodes"] >= st[k]["rays"] and st[k]["leaf_fetches"] > 0
+    assert st["any"]["aux_rows"] == 0
+    assert ctx.read_traversal_stats()["closest"]["rays"] == 0      # read and zeroed
