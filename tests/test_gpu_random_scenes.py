@@ -55,7 +55,10 @@ def random_scene(seed, n_sph, n_pl, n_light, w=56, h=40, spp=12):
 
 CASES = [(0, 1, 0, 1), (1, 0, 1, 1), (2, 3, 1, 2), (3, 4, 2, 1), (4, 5, 3, 3), (5, 7, 5, 2), (6, 8, 4, 5),
          (7, 9, 0, 1), (8, 0, 7, 2), (9, 13, 6, 4), (10, 31, 9, 2), (11, 63, 11, 1),
-         (12, 4, 3, 10)]  # more lights than the megakernel keeps occluder hints for
+         (12, 4, 3, 10),  # more lights than the megakernel keeps occluder hints for
+         # seeds picked (CPU oracle scan) so that >= 25 % of the pixels are lit; seeds 0, 1 and 11 above render black
+         # images (one-sided light facing away), which stay as the all-zero edge case
+         (2, 0, 1, 1), (7, 63, 11, 1), (26, 3, 1, 2), (20, 31, 9, 2)]
 
 
 @pytest.mark.parametrize("seed,n_sph,n_pl,n_light", CASES)
@@ -104,7 +107,8 @@ def test_random_scene_render_and_hits(oracle, hip, seed, n_sph, n_pl, n_light):
         assert np.quantile(r, 0.5) < 1e-5, np.quantile(r, [0.5, 0.8, 0.95])
         assert np.quantile(r, 0.8) < 1e-3, np.quantile(r, [0.5, 0.8, 0.95])
         tot_h, tot_o = acc.sum(dtype=np.float64), acc_o.sum(dtype=np.float64)
-        assert abs(tot_h - tot_o) <= 2e-2 * abs(tot_o) + 1e-6, (tot_h, tot_o)
+        # image totals: measured <= 3e-5 relative on every case at 12 and at 48 spp (tools/diag_random_scenes.py)
+        assert abs(tot_h - tot_o) <= 1e-3 * abs(tot_o) + 1e-6, (tot_h, tot_o)
     # wavefront variant renders the same image as the megakernel
     if n_sph < 64:
         from pathtracer_amd import _abi

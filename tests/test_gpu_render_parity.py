@@ -4,8 +4,10 @@ Both sides draw the same uniforms in the same order, so the comparison is
 sample-for-sample, not statistical: pixels agree to rounding except where a
 last-bit difference flips a branch (hit/miss at a grazing ray, u < R at a glass
 vertex, Russian roulette), which changes that one sample's path.
-Tolerances: BASELINE.json north_star — mean radiance within 1 % (we hold 0.1 %),
-per-pixel differences at/below the noise floor.
+Tolerances: BASELINE.json north_star — mean radiance within 1 %. Held here: 0.5 % on the raw mean of the
+example scene at 64 spp (a handful of ill-conditioned mirror highlights carry the difference, see _compare),
+0.01 % with the 0.5 % most different pixels left out and 0.01 % on the raw mean of the matte variant;
+per-pixel differences at/below rounding for the quantiles _compare names.
 """
 import os
 
