@@ -65,8 +65,9 @@ def test_c4_100k_spheres_lbvh_1080p(oracle):
     Hit records are bit-identical to the reference's (tests/test_gpu_unit_parity.py), but a path that
     bounces among spheres of radius 0.05-0.35 at distances of 5-50 amplifies a last-bit difference in a
     sampled direction by ~distance/radius per bounce, so only the first vertex (camera hit + next-event
-    estimation through the LBVH) is compared pixel by pixel; complete paths are compared through the
-    paired mean over the sampled pixels."""
+    estimation through the LBVH) is compared pixel by pixel with the oracle; complete paths are compared with the
+    oracle through the paired mean over the sampled pixels, and pixel by pixel with the same kernel arithmetic
+    run over the brute-force loops (part c), which separates the tree from the amplification."""
     from pathtracer_amd.synthetic import synthetic_spheres
     from pathtracer_amd import hip_renderer
     s = synthetic_spheres(100000, 0x5EED, 1920, 1080, 256)
@@ -89,8 +90,18 @@ def test_c4_100k_spheres_lbvh_1080p(oracle):
     got = acc[ys, xs].astype(np.float64).sum(axis=1)
     d = got - ref
     close = np.abs(d) <= 1e-4 * np.maximum(np.abs(ref), 2e-3)
-    assert close.mean() > 0.6, close.mean()
+    assert close.mean() > 0.6, close.mean()       # measured 0.706 (0.64 within 1e-6): tools/diag_c4_paths.py
     assert abs(d.mean()) <= 4.0 * d.std() / np.sqrt(n) + 1e-9, (d.mean(), d.std() / np.sqrt(n))
+    # (c) that the remaining differences come from the sampled directions' last bits and not from the tree: the
+    # same kernel arithmetic with the brute-force loops (no LBVH, 100 000 sphere tests per ray) renders the
+    # same complete paths at the full size, pixel by pixel
+    from pathtracer_amd import _abi
+    one = hip_renderer.render_accum(s, 255, 1, seed=0)
+    brute = hip_renderer.render_accum(s, 255, 1, seed=0, flags=_abi.FLAG_NO_BVH)
+    e = np.abs(one.astype(np.float64) - brute).max(axis=2) / np.maximum(np.abs(brute).max(axis=2), 1e-3)
+    assert np.quantile(e, 0.99) < 1e-5 and (e < 1e-4).mean() > 0.995, (np.quantile(e, [0.5, 0.99, 0.999]), (e < 1e-4).mean())
+    tot = brute.sum(dtype=np.float64)
+    assert tot > 0 and abs(one.sum(dtype=np.float64) - tot) <= 1e-3 * tot, (one.sum(dtype=np.float64), tot)
 
 
 def test_c5_8k_showcase_sample_indices(oracle):
