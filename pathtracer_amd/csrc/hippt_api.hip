@@ -258,6 +258,8 @@ struct hippt_context {
     int bvh_error_code = HIPPT_OK;
     float *slice_buf = nullptr;  // partial sums of sample slices (launch_megakernel)
     size_t slice_bytes = 0;
+    hipStream_t stream2 = nullptr;  // second pipeline of the LBVH queue variant (forked from / joined to the launch stream)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void *chunk_buf = nullptr;  // device staging of the progressive entry points
     size_t chunk_bytes = 0;
     // kernel timing (events on the launch stream)
@@ -301,6 +303,10 @@ int hippt_destroy(hippt_context *ctx) {
         (void)hipEventDestroy(p.second);
     }
     pt::bvh_free(ctx->bvh);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->wf_ws) (void)hipFree(ctx->wf_ws);
     if (ctx->chunk_buf) (void)hipFree(ctx->chunk_buf);
     if (ctx->slice_buf) (void)hipFree(ctx->slice_buf);
@@ -400,6 +406,11 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
             HIP_TRY(hipMalloc(&ctx->wf_ws, need));
             ctx->wf_ws_bytes = need;
         }
+        if (use_bvh && !ctx->stream2) {
+            HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
         const size_t need_slices = P.wf_streams_log2 ? ((size_t)pixels * 3 * sizeof(float)) << P.wf_streams_log2 : 0;
         if (need_slices > ctx->slice_bytes) {
             HIP_TRY(hipStreamSynchronize(st));
@@ -431,7 +442,7 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
             Pc.wf_streams_log2 = std::min(P.wf_streams_log2, pt::wfb_streams_log2((uint32_t)pixels, c, P.n_light));
             HIP_TRY(pt::wavefront_bvh_render(Pc, ctx->d_blob, bvh_view(ctx->bvh), stack_entries, d_accum, ctx->wf_ws, st, nullptr,
                                              (o.flags & HIPPT_FLAG_TRAVERSAL_STATS) ? ctx->d_counters + HIPPT_N_COUNTERS : nullptr,
-                                             ctx->slice_buf));
+                                             ctx->slice_buf, ctx->stream2, ctx->ev_fork, ctx->ev_join));
         }
         else if (wavefront)
             HIP_TRY(pt::wavefront_render(P, ctx->d_blob, d_accum, ctx->wf_ws, st, nullptr));

@@ -25,7 +25,8 @@ size_t wfb_workspace_bytes(uint32_t n_pixels, uint32_t n_light);
 // stats (optional, device, 8 x u64): {rays, nodes, leaf fetches, aux rows} of the closest-hit and of the any-hit traversals
 hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &bvh, uint32_t stack_entries, float *accum,
                                 void *workspace, hipStream_t st, uint32_t *iterations_out, unsigned long long *stats = nullptr,
-                                float *partial = nullptr);
+                                float *partial = nullptr, hipStream_t st2 = nullptr, hipEvent_t ev_fork = nullptr,
+                                hipEvent_t ev_join = nullptr);
 // sample streams per pixel (log2) for a launch of sample_count samples over n_pixels pixels: ~32 M paths in flight
 uint32_t wfb_streams_log2(uint32_t n_pixels, uint32_t sample_count, uint32_t n_light);
 // accum[i] += slice 0 + slice 1 + ... (fixed order) of `partial` (slices x n floats)
