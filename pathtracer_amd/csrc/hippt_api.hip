@@ -436,7 +436,11 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
         }
         auto &ev = ctx->ev_pool[ctx->ev_used++];
         HIP_TRY(hipEventRecord(ev.first, st));
+#ifdef HIPPT_STACK_OVERRIDE  // experiment only: more resident traversal waves (wrong images if a ray's stack overflows)
+        const uint32_t stack_entries = HIPPT_STACK_OVERRIDE;
+#else
         const uint32_t stack_entries = (uint32_t)std::min(pt::BVH_STACK, std::max(8, ctx->bvh_depth + 2));
+#endif
         if (wavefront && use_bvh) {
             pt::Params Pc = P;  // a short last chunk may have fewer samples than streams
             Pc.wf_streams_log2 = std::min(P.wf_streams_log2, pt::wfb_streams_log2((uint32_t)pixels, c, P.n_light));

@@ -12,10 +12,17 @@
 
 namespace pt {
 
-// Node = 2 x uint4 (32 B): per child {lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, child},
-// box faces on a 16-bit grid over the root box, rounded outwards at build time (pt_bvh_build.hip) — the
-// traversal kernels are bound by the number of vector-L1 accesses per node (each lane reads its own node:
-// one access per lane and 16-byte load), so two loads per node instead of four is what matters.
+// Node = 2 x uint4 (32 B): per child {c.x | c.y << 16, c.z | h.x << 16, h.y | h.z << 16, child} — the child box as
+// CENTRE c and HALF-SIZE h, six IEEE half floats in node units (u = (world - g_lo) / g_cell, g_lo = centre of the
+// root box, |u| <= 1024). Why this format: the traversal kernels are bound by VALU issue (~80 % busy on C4), and
+//   * v_fma_mix_f32 reads a half straight out of either half of a register, so decoding costs nothing, where a
+//     16-bit integer grid cost one half-rate v_cvt per face (12 per node);
+//   * with t_c = c * slope + off the two faces of an axis are t_c -+ h * |slope|: three full-rate FMAs per axis
+//     instead of two FMAs plus a half-rate min and max to order the faces.
+// The centre is rounded to nearest (<= 1/4 node unit at the far ends of the root box, less towards its centre, i.e.
+// <= 0.6 % of the smaller root half-extents... exactly: half an ulp of a half float) and the half-size is rounded UP
+// after that error and the build / traversal rounding margins have been added to it (pt_bvh_build.hip: k_pack), so a
+// decoded box always contains the exact one: boxes may only prune.
 // child >= 0: internal node index; child < 0: leaf ~child = position in the
 // Morton-sorted sphere arrays.
 // The first kBvhTopLevels levels of the tree are ALSO kept as a complete binary heap (slot 0 = root, children of
@@ -38,28 +45,27 @@ struct Bvh {
     const float4 *__restrict__ sph;  // sorted {c, r*r}
     const float4 *__restrict__ aux;  // sorted {1/r, material, scene order, 0}
     uint32_t n;                      // number of spheres (>= 2)
-    float g_lo[3], g_cell[3];        // box coordinate = g_lo + q * g_cell
+    float g_lo[3], g_cell[3];        // world = g_lo + u * g_cell (u: node units of the child boxes)
 };
 
-// Child boxes stay in GRID units (the 16-bit integers as floats); the ray is brought into grid units once, when it
-// starts its traversal: world = g_lo + q * cell, so the slab distance (world - ro) / rd is
-//     t(q) = q * (cell / rd) + (g_lo - ro) / rd = fma(q, slope, off),
-// one fma per box face with per-ray slope / off instead of decode-fma + subtract + multiply per face (the traversal
-// kernels are bound by instruction issue: 130 VALU instructions per node visit at 50 % lane occupancy).
-// Rounding: t(q) is off by <= ~2e-7 (65536 + |ro - g_lo| / cell) grid steps, far below the outward margin of the
-// boxes (>= 2 steps, pt_bvh_build.hip), so a box still never rejects a hit its sphere test accepts.
+// Child boxes stay in NODE units; the ray is brought into node units once, when it starts its traversal:
+// world = g_lo + u * g_cell, so the slab distance (world - ro) / rd is
+//     t(u) = u * (cell / rd) + (g_lo - ro) / rd = fma(u, slope, off).
+// Rounding: each t is off by a few 1e-7 (|u| + |ro - g_lo| / cell) node units, far below the margin added to the
+// half-sizes (>= 1/32 node unit, pt_bvh_build.hip), so a box still never rejects a hit its sphere test accepts.
 struct NodeBoxes {
-    F3 llo, lhi, rlo, rhi;  // grid units
+    F3 lc, lh, rc, rh;  // centre and half-size of the left / right child box, node units
     int left, right;
 };
 __device__ __forceinline__ NodeBoxes decode_node(uint4 a, uint4 b) {
-    auto lo16 = [](uint32_t v) { return (float)(v & 0xffffu); };
-    auto hi16 = [](uint32_t v) { return (float)(v >> 16); };
+    // (float) of a half taken from the low / high 16 bits: folded into v_fma_mix_f32's operand selection
+    auto lo16 = [](uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v & 0xffffu)); };
+    auto hi16 = [](uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16)); };
     NodeBoxes nb;
-    nb.llo = F3{lo16(a.x), hi16(a.x), lo16(a.y)};
-    nb.lhi = F3{hi16(a.y), lo16(a.z), hi16(a.z)};
-    nb.rlo = F3{lo16(b.x), hi16(b.x), lo16(b.y)};
-    nb.rhi = F3{hi16(b.y), lo16(b.z), hi16(b.z)};
+    nb.lc = F3{lo16(a.x), hi16(a.x), lo16(a.y)};
+    nb.lh = F3{hi16(a.y), lo16(a.z), hi16(a.z)};
+    nb.rc = F3{lo16(b.x), hi16(b.x), lo16(b.y)};
+    nb.rh = F3{hi16(b.y), lo16(b.z), hi16(b.z)};
     nb.left = (int)a.w;
     nb.right = (int)b.w;
     return nb;
@@ -68,25 +74,27 @@ __device__ __forceinline__ NodeBoxes load_node(const Bvh &B, int node) {
     return decode_node(B.nodes[node * 2 + 0], B.nodes[node * 2 + 1]);
 }
 
-
 constexpr int BVH_STACK = 48;  // entries per lane (LDS); deeper trees raise an error at build time
 
 struct BoxRay {
-    F3 slope, off;  // t(q) = fma(q, slope, off) per axis
+    F3 slope, off, aslope;  // t(u) = fma(u, slope, off) per axis; aslope = |slope|
 };
 __device__ __forceinline__ BoxRay make_box_ray(const Bvh &B, F3 ro, F3 rd) {
     auto safe = [](float d) { return fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d; };
     const F3 inv = F3{rcp(safe(rd.x)), rcp(safe(rd.y)), rcp(safe(rd.z))};
-    return BoxRay{F3{B.g_cell[0] * inv.x, B.g_cell[1] * inv.y, B.g_cell[2] * inv.z},
-                  F3{(B.g_lo[0] - ro.x) * inv.x, (B.g_lo[1] - ro.y) * inv.y, (B.g_lo[2] - ro.z) * inv.z}};
+    const F3 slope = F3{B.g_cell[0] * inv.x, B.g_cell[1] * inv.y, B.g_cell[2] * inv.z};
+    return BoxRay{slope, F3{(B.g_lo[0] - ro.x) * inv.x, (B.g_lo[1] - ro.y) * inv.y, (B.g_lo[2] - ro.z) * inv.z},
+                  F3{fabsf(slope.x), fabsf(slope.y), fabsf(slope.z)}};
 }
-// Entry distance of the ray into the box (grid units), +inf if it misses or lies beyond t_max / behind the origin.
-__device__ __forceinline__ float box_entry(const BoxRay &b, F3 lo, F3 hi, float t_max) {
-    float x0 = fmaf(lo.x, b.slope.x, b.off.x), x1 = fmaf(hi.x, b.slope.x, b.off.x);
-    float y0 = fmaf(lo.y, b.slope.y, b.off.y), y1 = fmaf(hi.y, b.slope.y, b.off.y);
-    float z0 = fmaf(lo.z, b.slope.z, b.off.z), z1 = fmaf(hi.z, b.slope.z, b.off.z);
-    float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-    float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_max));
+// Entry distance of the ray into the box (centre c, half-size h, node units), +inf if it misses or lies beyond
+// t_max / behind the origin.
+__device__ __forceinline__ float box_entry(const BoxRay &b, F3 c, F3 h, float t_max) {
+    const float cx = fmaf(c.x, b.slope.x, b.off.x), cy = fmaf(c.y, b.slope.y, b.off.y), cz = fmaf(c.z, b.slope.z, b.off.z);
+    const float nx = fmaf(-h.x, b.aslope.x, cx), fx = fmaf(h.x, b.aslope.x, cx);
+    const float ny = fmaf(-h.y, b.aslope.y, cy), fy = fmaf(h.y, b.aslope.y, cy);
+    const float nz = fmaf(-h.z, b.aslope.z, cz), fz = fmaf(h.z, b.aslope.z, cz);
+    float tmin = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+    float tmax = fminf(fminf(fx, fy), fminf(fz, t_max));
     return tmin <= tmax ? tmin : __builtin_inff();
 }
 
@@ -112,8 +120,8 @@ __device__ __forceinline__ void bvh_closest(const Bvh &B, const RayK &r, float &
         NodeBoxes nb = load_node(B, node);
         int left = nb.left, right = nb.right;
         // boxes are tested against best_t inclusively: a sphere that ties must still be visited
-        float tl = box_entry(br, nb.llo, nb.lhi, best_t);
-        float tr = box_entry(br, nb.rlo, nb.rhi, best_t);
+        float tl = box_entry(br, nb.lc, nb.lh, best_t);
+        float tr = box_entry(br, nb.rc, nb.rh, best_t);
         bool hl = tl < __builtin_inff(), hr = tr < __builtin_inff();
         const bool ll = hl && left < 0, rl = hr && right < 0;
         if (ll || rl) {  // both leaf spheres are fetched at once (one memory latency, not two)
@@ -149,8 +157,8 @@ __device__ __forceinline__ bool bvh_any(const Bvh &B, const RayK &r, float lim, 
     for (;;) {
         NodeBoxes nb = load_node(B, node);
         int left = nb.left, right = nb.right;
-        bool hl = box_entry(br, nb.llo, nb.lhi, t_max) < __builtin_inff();
-        bool hr = box_entry(br, nb.rlo, nb.rhi, t_max) < __builtin_inff();
+        bool hl = box_entry(br, nb.lc, nb.lh, t_max) < __builtin_inff();
+        bool hr = box_entry(br, nb.rc, nb.rh, t_max) < __builtin_inff();
         const bool ll = hl && left < 0, rl = hr && right < 0;
         if (ll || rl) {  // both leaf spheres at once; a lone leaf is read twice and counted once
             const int il = ll ? ~left : ~right, ir = rl ? ~right : ~left;

@@ -7,7 +7,7 @@ namespace pt {
 
 struct BvhBuffers {
     uint4 *nodes = nullptr;        // (n-1) x 2 uint4: 32-byte nodes, child boxes on a 16-bit grid (pt_bvh.h)
-    float grid_lo[3] = {0, 0, 0};  // box coordinate = grid_lo + q * grid_cell, q = 0..65535
+    float grid_lo[3] = {0, 0, 0};  // world = grid_lo + u * grid_cell, u = node units of the packed child boxes (pt_bvh.h)
     float grid_cell[3] = {0, 0, 0};
     uint4 *top = nullptr;          // the first kBvhTopLevels levels again, heap order, for the traversal kernels' LDS copy (pt_bvh.h)
     float4 *sph_sorted = nullptr;  // n x {c, r*r}, Morton order

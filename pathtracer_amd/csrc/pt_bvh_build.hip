@@ -7,7 +7,7 @@
 //   4. Karras 2012 binary radix tree over keys (code << 32 | sorted position)
 //   5. leaf boxes, then bottom-up refit, one launch per level (a kernel boundary is the
 //      only inter-workgroup ordering relied upon: no in-launch flags, cf. guide G16)
-//   6. pack 64-byte traversal nodes {left box, right box, children}
+//   6. pack 32-byte traversal nodes {left box, right box, children} (half-float centre / half-size boxes)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -150,21 +150,26 @@ __global__ void k_copy_ready(int n_nodes, const int *__restrict__ src, int *dst)
     if (i < n_nodes) dst[i] = src[i];
 }
 
-// 32-byte node: {L.lo.x | L.lo.y << 16, L.lo.z | L.hi.x << 16, L.hi.y | L.hi.z << 16, left}
-//               {R ... , right}. A box face is stored on a grid of 65536 steps over the root box and moved
-// OUTWARDS by `margin` steps beyond the step that contains it, so that the decoded box (g_lo + q * cell,
-// evaluated in f32 by the traversal) always contains the exact one: boxes may only prune.
+// 32-byte node (pt_bvh.h): per child {c.x | c.y << 16, c.z | h.x << 16, h.y | h.z << 16, child}, half floats in node
+// units u = (world - ctr) * inv_unit. The exact box is first widened by `margin` node units (f32 rounding of the
+// build-side (v - ctr) * inv and of the traversal-side t = fma(u, slope, off), see bvh_build), the centre is rounded to
+// the nearest half and the half-size is then rounded UP from what that centre needs to cover the widened box, so
+// that the decoded box always contains the exact one: boxes may only prune.
 struct Grid {
-    float lo[3], cell[3], inv_cell[3];
-    int margin;
+    float ctr[3], unit[3], inv_unit[3];
+    float margin;
 };
-__device__ __forceinline__ uint32_t q_lo(float v, float g, float inv, int margin) {
-    int q = (int)floorf((v - g) * inv) - margin;
-    return (uint32_t)max(0, min(65535, q));
-}
-__device__ __forceinline__ uint32_t q_hi(float v, float g, float inv, int margin) {
-    int q = (int)ceilf((v - g) * inv) + margin;
-    return (uint32_t)max(0, min(65535, q));
+__device__ __forceinline__ uint32_t half_bits(_Float16 h) { return (uint32_t)__builtin_bit_cast(unsigned short, h); }
+__device__ __forceinline__ void pack_axis(float blo, float bhi, float ctr, float inv, float margin, uint32_t &c_bits, uint32_t &h_bits) {
+    const float ulo = (blo - ctr) * inv - margin, uhi = (bhi - ctr) * inv + margin;
+    const _Float16 c = (_Float16)(0.5f * (ulo + uhi));  // round to nearest
+    const float cf = (float)c;
+    const float need = fmaxf(uhi - cf, cf - ulo) * 1.000001f;  // the two subtractions round, too
+    _Float16 h = (_Float16)fminf(need, 60000.0f);
+    uint32_t hb = half_bits(h);
+    if ((float)h < need) ++hb;  // next half up (positive, finite: the bit pattern is monotonic)
+    c_bits = half_bits(c);
+    h_bits = hb;
 }
 __global__ void k_pack(int n, const int *__restrict__ left, const int *__restrict__ right, const float4 *__restrict__ lo,
                        const float4 *__restrict__ hi, Grid G, uint4 *nodes) {
@@ -174,11 +179,11 @@ __global__ void k_pack(int n, const int *__restrict__ left, const int *__restric
     int li = l < 0 ? n - 1 + ~l : l, ri = r < 0 ? n - 1 + ~r : r;
     float4 a = lo[li], b = hi[li], c = lo[ri], d = hi[ri];
     auto pack = [&](float4 blo, float4 bhi, int child) {
-        uint32_t lx = q_lo(blo.x, G.lo[0], G.inv_cell[0], G.margin), ly = q_lo(blo.y, G.lo[1], G.inv_cell[1], G.margin),
-                 lz = q_lo(blo.z, G.lo[2], G.inv_cell[2], G.margin);
-        uint32_t hx = q_hi(bhi.x, G.lo[0], G.inv_cell[0], G.margin), hy = q_hi(bhi.y, G.lo[1], G.inv_cell[1], G.margin),
-                 hz = q_hi(bhi.z, G.lo[2], G.inv_cell[2], G.margin);
-        return make_uint4(lx | (ly << 16), lz | (hx << 16), hy | (hz << 16), (uint32_t)child);
+        uint32_t cx, cy, cz, hx, hy, hz;
+        pack_axis(blo.x, bhi.x, G.ctr[0], G.inv_unit[0], G.margin, cx, hx);
+        pack_axis(blo.y, bhi.y, G.ctr[1], G.inv_unit[1], G.margin, cy, hy);
+        pack_axis(blo.z, bhi.z, G.ctr[2], G.inv_unit[2], G.margin, cz, hz);
+        return make_uint4(cx | (cy << 16), cz | (hx << 16), hy | (hz << 16), (uint32_t)child);
     };
     nodes[i * 2 + 0] = pack(a, b, l);
     nodes[i * 2 + 1] = pack(c, d, r);
@@ -302,30 +307,31 @@ hipError_t bvh_build(const float4 *d_sph, const float4 *d_aux, uint32_t n, BvhBu
         total += d;
         std::swap(ready_a.p, ready_b.p);
     }
-    // quantisation grid over the root box (internal node 0)
+    // node units over the root box (internal node 0): its centre is the origin, its half-extents are 1024 units
     float4 root_lo, root_hi;
     BVH_TRY(hipMemcpyAsync(&root_lo, lo.p, 16, hipMemcpyDeviceToHost, st));
     BVH_TRY(hipMemcpyAsync(&root_hi, hi.p, 16, hipMemcpyDeviceToHost, st));
     BVH_TRY(hipStreamSynchronize(st));
     Grid G;
     const float rl[3] = {root_lo.x, root_lo.y, root_lo.z}, rh[3] = {root_hi.x, root_hi.y, root_hi.z};
-    double max_abs = 0.0, min_cell = INFINITY;
+    double max_abs = 0.0, min_unit = INFINITY;
     for (int k = 0; k < 3; ++k) {
-        double ext = std::max((double)rh[k] - (double)rl[k], 1e-30);
-        double cell = ext / 65000.0;  // the faces keep a few hundred steps of room for the outward margin
-        G.lo[k] = (float)((double)rl[k] - 256.0 * cell);
-        G.cell[k] = (float)cell;
-        G.inv_cell[k] = (float)(1.0 / cell);
+        double half = std::max(0.5 * ((double)rh[k] - (double)rl[k]), 1e-30);
+        double unit = half / 1024.0;
+        G.ctr[k] = (float)(0.5 * ((double)rh[k] + (double)rl[k]));
+        G.unit[k] = (float)unit;
+        G.inv_unit[k] = (float)(1.0 / unit);
         max_abs = std::max({max_abs, std::fabs((double)rl[k]), std::fabs((double)rh[k])});
-        min_cell = std::min(min_cell, cell);
+        min_unit = std::min(min_unit, unit);
     }
-    if (!std::isfinite(max_abs) || !std::isfinite(min_cell)) return hipErrorInvalidValue;
-    // f32 rounding of (v - g) * inv at build time and of g + q * cell at traversal time: a few ulps of the largest
-    // coordinate, expressed in grid steps, plus one
-    G.margin = 2 + (int)std::min(200.0, std::ceil(8.0 * max_abs * 1.2e-7 / min_cell));  // + 1 step for the ray-side rounding of t(q) = fma(q, slope, off), pt_bvh.h
+    if (!std::isfinite(max_abs) || !std::isfinite(min_unit)) return hipErrorInvalidValue;
+    // f32 rounding of (v - ctr) * inv at build time: a few ulps of the largest coordinate, in node units; plus 1/32 unit
+    // for the ray-side rounding of t(u) = fma(u, slope, off) and of the face offsets (pt_bvh.h), which covers ray
+    // origins up to ~250 root half-extents away from the root's centre
+    G.margin = (float)(1.0 / 32.0 + std::min(64.0, 8.0 * max_abs * 1.2e-7 / min_unit));
     for (int k = 0; k < 3; ++k) {
-        out.grid_lo[k] = G.lo[k];
-        out.grid_cell[k] = G.cell[k];
+        out.grid_lo[k] = G.ctr[k];
+        out.grid_cell[k] = G.unit[k];
     }
     hipLaunchKernelGGL(k_pack, dim3(g), dim3(bs), 0, st, N, (const int *)left.p, (const int *)right.p, (const float4 *)lo.p,
                        (const float4 *)hi.p, G, out.nodes);

@@ -223,8 +223,8 @@ __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q,
         if (STATS) ++st_nodes;
         int left = nb.left, right = nb.right;
         const float bound = ANY ? t_max : best_t;
-        float tl = box_entry(br, nb.llo, nb.lhi, bound);
-        float tr = box_entry(br, nb.rlo, nb.rhi, bound);
+        float tl = box_entry(br, nb.lc, nb.lh, bound);
+        float tr = box_entry(br, nb.rc, nb.rh, bound);
         bool hl = tl < __builtin_inff(), hr = tr < __builtin_inff();
         bool finished = false;
         if (ANY) {
@@ -706,6 +706,13 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
     const size_t stack_bytes = (size_t)kBvhTopSlots * 32 + (size_t)stack_entries * kTravThreads * 4;
     hipError_t e;
     if (P.sample_count == 0) return hipSuccess;
+    if (stack_bytes > 64 * 1024) {  // more dynamic LDS than a launch may ask for by default
+        const int b = (int)stack_bytes;
+        if ((e = hipFuncSetAttribute((const void *)WFB_TRAV<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void *)WFB_TRAV<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void *)WFB_TRAV<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void *)WFB_TRAV<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
+    }
     if (n_groups > 1) {
         if ((e = hipEventRecord(ev_fork, st)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(st2, ev_fork, 0)) != hipSuccess) return e;

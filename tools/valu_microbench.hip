@@ -12,7 +12,32 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k(float *out, float a, float b, unsigned long long *cyc) {
     unsigned long long c0 = __builtin_readcyclecounter();  // s_memtime: shader-clock ticks
     float x0 = threadIdx.x * 1e-3f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    float x0b = threadIdx.x * 3e-3f;
     for (int i = 0; i < ITER; ++i) {
+        if (MODE == 40) {
+            asm volatile("v_perm_b32 %0, %9, %0, %10\n v_perm_b32 %1, %9, %1, %10\n v_perm_b32 %2, %9, %2, %10\n v_perm_b32 %3, %9, %3, %10\n v_perm_b32 %4, %9, %4, %10\n v_perm_b32 %5, %9, %5, %10\n v_perm_b32 %6, %9, %6, %10\n v_perm_b32 %7, %9, %7, %10\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a), "v"(b), "v"(x0b));
+        }
+        if (MODE == 41) {
+            asm volatile("v_and_or_b32 %0, %0, %9, %10\n v_and_or_b32 %1, %1, %9, %10\n v_and_or_b32 %2, %2, %9, %10\n v_and_or_b32 %3, %3, %9, %10\n v_and_or_b32 %4, %4, %9, %10\n v_and_or_b32 %5, %5, %9, %10\n v_and_or_b32 %6, %6, %9, %10\n v_and_or_b32 %7, %7, %9, %10\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a), "v"(b), "v"(x0b));
+        }
+        if (MODE == 42) {
+            asm volatile("v_cvt_f32_u32_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %2, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %3, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %4, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %5, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %6, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %7, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a), "v"(b), "v"(x0b));
+        }
+        if (MODE == 43) {
+            asm volatile("v_cvt_f32_ubyte1 %0, %0\n v_cvt_f32_ubyte1 %1, %1\n v_cvt_f32_ubyte1 %2, %2\n v_cvt_f32_ubyte1 %3, %3\n v_cvt_f32_ubyte1 %4, %4\n v_cvt_f32_ubyte1 %5, %5\n v_cvt_f32_ubyte1 %6, %6\n v_cvt_f32_ubyte1 %7, %7\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a), "v"(b), "v"(x0b));
+        }
+        if (MODE == 44) {
+            asm volatile("v_cvt_f32_f16 %0, %0\n v_cvt_f32_f16 %1, %1\n v_cvt_f32_f16 %2, %2\n v_cvt_f32_f16 %3, %3\n v_cvt_f32_f16 %4, %4\n v_cvt_f32_f16 %5, %5\n v_cvt_f32_f16 %6, %6\n v_cvt_f32_f16 %7, %7\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a), "v"(b), "v"(x0b));
+        }
+        if (MODE == 45) {
+            asm volatile("v_perm_b32 %0, %9, %0, %8\n v_perm_b32 %1, %9, %1, %8\n v_perm_b32 %2, %9, %2, %8\n v_perm_b32 %3, %9, %3, %8\n v_perm_b32 %4, %9, %4, %8\n v_perm_b32 %5, %9, %5, %8\n v_perm_b32 %6, %9, %6, %8\n v_perm_b32 %7, %9, %7, %8\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a), "v"(b), "v"(x0b));
+        }
         if (MODE == 0) {  // 8 independent fma chains
             asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
                          "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
@@ -191,7 +216,15 @@ int main() {
     unsigned long long *dc;
     hipMalloc(&d, 256 * 8 * 2048 * sizeof(float));
     hipMalloc(&dc, 256 * 8 * 4 * sizeof(unsigned long long));
+    run<40>("v_perm_b32 (vgpr selector)", d, dc);
+    run<45>("v_perm_b32 (sgpr selector)", d, dc);
+    run<41>("v_and_or_b32", d, dc);
+    run<42>("v_cvt_f32_u32_sdwa WORD_1", d, dc);
+    run<43>("v_cvt_f32_ubyte1", d, dc);
+    run<44>("v_cvt_f32_f16", d, dc);
     run<0>("fma independent", d, dc);
+    run<24>("v_cvt_f32_u32", d, dc);
+    return 0;
     run<1>("fma dependent chain", d, dc);
     run<2>("mul/add independent", d, dc);
     run<3>("cmp+cndmask", d, dc);
