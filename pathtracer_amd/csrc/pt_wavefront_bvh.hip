@@ -30,6 +30,8 @@
 //
 // The arithmetic is the device code of the megakernels (pt_device.h, pt_bvh.h) with the same RNG stream
 // per (pixel, sample) and the same draw order, so the image equals the BVH megakernel's.
+#include <cstdlib>
+
 #include "pt_kernels.h"
 #include "pt_trace.h"
 #include "pt_wfqueue.h"
@@ -137,13 +139,19 @@ __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q,
                                                     const uint32_t *__restrict__ ray_list, const uint32_t *__restrict__ ray_count,
                                                     uint32_t *__restrict__ head,
                                                     float *__restrict__ hit_t, int *__restrict__ hit_leaf,
-                                                    uint8_t *__restrict__ occ_out, unsigned long long *__restrict__ stats = nullptr) {
+                                                    uint8_t *__restrict__ occ_out, unsigned long long *__restrict__ stats,
+                                                    uint32_t lds_entries, uint32_t *__restrict__ spill) {
     uint32_t st_rays = 0, st_nodes = 0, st_leaves = 0, st_aux = 0, st_top = 0;
     extern __shared__ uint4 s_top[];  // the tree's first levels (kBvhTopSlots x 2 uint4), then stack_entries x kTravThreads words
     for (uint32_t i = threadIdx.x; i < 2u * kBvhTopSlots; i += kTravThreads) s_top[i] = bvh.top[i];
     __syncthreads();
     uint32_t *stack = reinterpret_cast<uint32_t *>(s_top + 2 * kBvhTopSlots) + threadIdx.x;
     const uint32_t stride = kTravThreads;
+    // Stack entries beyond the first lds_entries live in this thread's column of a global spill area. The host sizes the
+    // LDS part so that 8 blocks fit a CU (18 entries; 23 would allow 6) — on C4 no ray goes deeper than 17, so the
+    // spill path is there for correctness on deeper trees, not for speed (+3.5 % from the two extra blocks per CU).
+    uint32_t *const spill_col = spill + (size_t)blockIdx.x * kTravThreads + threadIdx.x;
+    const size_t spill_stride = (size_t)gridDim.x * kTravThreads;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_rays = ANY ? *ray_count : *Q.count;
     const size_t cap = Q.cap;
@@ -270,7 +278,9 @@ __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q,
         if (!finished) {
             if (hl && hr) {
                 bool lfirst = (ANY && !WFB_ANY_NEAR_FIRST) ? true : (tl <= tr);
-                stack[sp * stride] = (uint32_t)(lfirst ? right : left);
+                const uint32_t other = (uint32_t)(lfirst ? right : left);
+                if ((uint32_t)sp < lds_entries) stack[sp * stride] = other;
+                else spill_col[((uint32_t)sp - lds_entries) * spill_stride] = other;
                 ++sp;
                 node = lfirst ? left : right;
             } else if (hl || hr) {
@@ -285,7 +295,12 @@ __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q,
                 }
             } else {
                 --sp;
-                node = (int)stack[sp * stride];
+                if (__builtin_expect((uint32_t)sp < lds_entries, 1)) {
+                    node = (int)stack[sp * stride];
+                } else {  // (the barrier keeps the two loads apart: merged, they become one flat load with a selected address)
+                    node = (int)spill_col[((uint32_t)sp - lds_entries) * spill_stride];
+                    asm volatile("" : "+v"(node));
+                }
             }
         }
         if (finished) has = false;
@@ -620,6 +635,12 @@ namespace {
 struct WfbLayout {
     size_t per_queue, hits, samples, occ, list, total;
 };
+constexpr unsigned kGridTrav = 256u * 8u * 256u / kTravThreads;  // persistent traversal blocks: every CU full
+constexpr uint32_t kLdsEntriesMax = (160u * 1024u / 8u - kBvhTopSlots * 32u) / (kTravThreads * 4u);  // 8 blocks per CU: 18
+// stack entries that do not fit the LDS part, one column per traversal thread, shared by all traversal launches of a stream
+size_t wfb_spill_bytes(uint32_t stack_entries) {
+    return stack_entries > kLdsEntriesMax ? (size_t)(stack_entries - kLdsEntriesMax) * kGridTrav * kTravThreads * 4 : 256;
+}
 WfbLayout wfb_layout(uint32_t n, uint32_t n_light) {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     WfbLayout L;
@@ -635,7 +656,8 @@ WfbLayout wfb_layout(uint32_t n, uint32_t n_light) {
 
 // room for one pipeline over n entries or two over n / 2 each
 size_t wfb_workspace_bytes(uint32_t n_pixels, uint32_t n_light) {
-    return std::max(wfb_layout(n_pixels, n_light).total, 2 * wfb_layout((n_pixels + 1) / 2, n_light).total);
+    return std::max(wfb_layout(n_pixels, n_light).total, 2 * wfb_layout((n_pixels + 1) / 2, n_light).total) +
+           2 * ((wfb_spill_bytes((uint32_t)BVH_STACK) + 255) & ~(size_t)255);
 }
 
 uint32_t wfb_streams_log2(uint32_t n_pixels, uint32_t sample_count, uint32_t n_light) {
@@ -674,11 +696,18 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
         float *hit_t, *samples;
         int *hit_leaf;
         uint8_t *occ;
-        uint32_t *ray_list;
+        uint32_t *ray_list, *spill;
         bool done;
     } G[2];
+    uint32_t lds_entries = std::min(stack_entries, kLdsEntriesMax);
+    if (const char *dbg = getenv("HIPPT_WFB_LDS_STACK")) {  // test hook: a small LDS part forces the spill path (tests/test_gpu_bvh.py)
+        const long v = strtol(dbg, nullptr, 10);
+        if (v >= 1 && (uint32_t)v < lds_entries && stack_entries - (uint32_t)v <= (uint32_t)BVH_STACK - kLdsEntriesMax) lds_entries = (uint32_t)v;
+    }
+    const size_t spill_bytes = (wfb_spill_bytes((uint32_t)BVH_STACK) + 255) & ~(size_t)255;
     for (uint32_t g = 0; g < n_groups; ++g) {
-        uint8_t *w = (uint8_t *)workspace + (size_t)g * L.total;
+        uint8_t *w = (uint8_t *)workspace + (size_t)g * (L.total + spill_bytes);
+        G[g].spill = (uint32_t *)(w + L.total);
         G[g].st = g ? st2 : st;
         G[g].counters = (uint32_t *)w;
         w += 4096;
@@ -702,8 +731,8 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
 
     const unsigned blocks_all = (n + 255) / 256;
     const unsigned grid = std::min(blocks_all, 256u * 8u);
-    const unsigned grid_trav = 256u * 8u * 256u / kTravThreads;  // persistent: every CU full
-    const size_t stack_bytes = (size_t)kBvhTopSlots * 32 + (size_t)stack_entries * kTravThreads * 4;
+    const unsigned grid_trav = kGridTrav;
+    const size_t stack_bytes = (size_t)kBvhTopSlots * 32 + (size_t)lds_entries * kTravThreads * 4;
     hipError_t e;
     if (P.sample_count == 0) return hipSuccess;
     if (stack_bytes > 64 * 1024) {  // more dynamic LDS than a launch may ask for by default
@@ -743,21 +772,21 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
             if ((e = hipMemsetAsync(&counters[2], 0, 16, s)) != hipSuccess) return join(e);  // shade count, both fetch heads, shadow-ray count
             if (stats)
                 hipLaunchKernelGGL((WFB_TRAV<false, true>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[cur], (const float *)nullptr,
-                                   (const uint32_t *)nullptr, (const uint32_t *)nullptr, &counters[3], A.hit_t, A.hit_leaf, (uint8_t *)nullptr, stats);
+                                   (const uint32_t *)nullptr, (const uint32_t *)nullptr, &counters[3], A.hit_t, A.hit_leaf, (uint8_t *)nullptr, stats, lds_entries, A.spill);
             else
                 hipLaunchKernelGGL((WFB_TRAV<false, false>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[cur], (const float *)nullptr,
                                    (const uint32_t *)nullptr, (const uint32_t *)nullptr, &counters[3], A.hit_t, A.hit_leaf, (uint8_t *)nullptr,
-                                   (unsigned long long *)nullptr);
+                                   (unsigned long long *)nullptr, lds_entries, A.spill);
             hipLaunchKernelGGL(wfb_logic, dim3(grid), dim3(256), 0, s, P, blob, bvh, A.Q[cur], (const float *)A.hit_t,
                                (const int *)A.hit_leaf, A.Q[1 - cur], A.Q[2], sums);
             hipLaunchKernelGGL(wfb_nee_gen, dim3(grid), dim3(256), 0, s, P, blob, A.Q[2], A.samples, A.occ, A.ray_list, &counters[5]);
             if (stats)
                 hipLaunchKernelGGL((WFB_TRAV<true, true>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[2], (const float *)A.samples,
-                                   (const uint32_t *)A.ray_list, (const uint32_t *)&counters[5], &counters[4], (float *)nullptr, (int *)nullptr, A.occ, stats);
+                                   (const uint32_t *)A.ray_list, (const uint32_t *)&counters[5], &counters[4], (float *)nullptr, (int *)nullptr, A.occ, stats, lds_entries, A.spill);
             else
                 hipLaunchKernelGGL((WFB_TRAV<true, false>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[2], (const float *)A.samples,
                                    (const uint32_t *)A.ray_list, (const uint32_t *)&counters[5], &counters[4], (float *)nullptr, (int *)nullptr, A.occ,
-                                   (unsigned long long *)nullptr);
+                                   (unsigned long long *)nullptr, lds_entries, A.spill);
             hipLaunchKernelGGL(wfb_shade, dim3(grid), dim3(256), 0, s, P, blob, A.Q[2], (const float *)A.samples, (const uint8_t *)A.occ,
                                A.Q[1 - cur], sums);
         }

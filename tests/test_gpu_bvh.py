@@ -185,3 +185,15 @@ def test_traversal_stats_of_the_queue_pipeline(scene20k):
         assert st[k]["nodes"] >= st[k]["rays"] and st[k]["leaf_fetches"] > 0
     assert st["any"]["aux_rows"] == 0
     assert ctx.read_traversal_stats()["closest"]["rays"] == 0      # read and zeroed
+
+
+def test_traversal_stack_spills_to_global_memory(scene20k, monkeypatch):
+    """The queue pipeline keeps at most 18 stack entries per ray in LDS (8 traversal blocks per CU) and the rest in a
+    global spill column; HIPPT_WFB_LDS_STACK lowers the LDS part so that the 20 000-sphere scene really spills: the
+    image must not change by a bit."""
+    from pathtracer_amd import hip_renderer
+    s = scene20k.with_render(160, 90, 4)
+    ref = hip_renderer.render_accum(s, seed=7)
+    monkeypatch.setenv("HIPPT_WFB_LDS_STACK", "2")
+    spilled = hip_renderer.render_accum(s, seed=7)
+    assert ref.mean() > 0 and np.array_equal(ref, spilled)
