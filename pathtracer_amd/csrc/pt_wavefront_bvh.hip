@@ -100,6 +100,20 @@ __device__ __forceinline__ void push_ray(const WfQueue &Q, uint32_t pos, uint32_
 
 }  // namespace
 
+// One light sample of renderer.rs:35-44 from its two uniforms: unit direction, distance limit of the shadow ray
+// (|lvec| sqrt(0.999), renderer.rs:46) and 1 / dist^2. wfb_nee_gen (for the shadow rays) and wfb_shade (for the
+// evaluation) both call it with the same uniforms instead of passing 20 bytes per sample through HBM; the operations
+// are spelt out so that both kernels round alike.
+__device__ __forceinline__ void light_sample(float4 l0, float4 l1, float4 l2, F3 x, float e1, float e2, F3 &l, float &tmax, float &inv_d2) {
+    const F3 lvec = F3{fmaf(l2.x, e2, fmaf(l1.x, e1, l0.x)) - x.x, fmaf(l2.y, e2, fmaf(l1.y, e1, l0.y)) - x.y,
+                       fmaf(l2.z, e2, fmaf(l1.z, e1, l0.z)) - x.z};
+    const float dist2 = fmaf(lvec.z, lvec.z, fmaf(lvec.y, lvec.y, lvec.x * lvec.x));
+    const float inv = rsq(dist2);
+    l = F3{lvec.x * inv, lvec.y * inv, lvec.z * inv};
+    tmax = (dist2 * inv) * 0.99949987493746f;
+    inv_d2 = inv * inv;
+}
+
 // Every stream starts with the camera path of its first sample; entries of the ray queue are always live rays.
 // The streams of a launch are dealt to 2^group_bits groups (the host's concurrent pipelines); group g owns the streams
 // whose top group_bits bits are g, and entry j of its queue is (pixel, stream) = (j >> (k - group_bits), g's j-th stream).
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q,
                     if (ANY) {
                         uint32_t ke = ray_list[ridx];  // sample k of shade-queue entry e, as k * cap + e
                         uint32_t k = ke / (uint32_t)cap, e = ke - k * (uint32_t)cap;
-                        const float *sp5 = samples + (size_t)k * 5 * cap + e;
+                        const float *sp5 = samples + (size_t)k * 4 * cap + e;
                         F3 l = F3{sp5[0], sp5[cap], sp5[2 * cap]};
                         float tmax = sp5[3 * cap];
                         F3 x = Q.ld3(F_X, e);
@@ -457,17 +471,14 @@ __global__ __launch_bounds__(256) void wfb_nee_gen(Params P, const float4 *__res
                 if (act) {
                     float e1 = rng.gen() - 0.5f;
                     float e2 = rng.gen() - 0.5f;
-                    F3 lp = f3(l0) + f3(l1) * e1 + f3(l2) * e2;
-                    F3 lvec = lp - x;
-                    float dist2 = dot(lvec, lvec);
-                    float inv = rsq(dist2);
-                    F3 l = lvec * inv;
-                    float *sp5 = samples + (size_t)k * 5 * cap + qi;
+                    F3 l;
+                    float tmax, inv_d2;
+                    light_sample(l0, l1, l2, x, e1, e2, l, tmax, inv_d2);
+                    float *sp5 = samples + (size_t)k * 4 * cap + qi;
                     sp5[0] = l.x;
                     sp5[cap] = l.y;
                     sp5[2 * cap] = l.z;
-                    sp5[3 * cap] = (dist2 * inv) * 0.99949987493746f;  // |lvec| sqrt(0.999)
-                    sp5[4 * cap] = inv * inv;
+                    sp5[3 * cap] = tmax;
                     want[s] = (dot(nn, l) > 0.0f) & (-dot(l, f3(l4)) > 0.0f);
                     if (!want[s]) occ[(size_t)k * cap + qi] = 1;
                 }
@@ -506,10 +517,7 @@ __global__ __launch_bounds__(256) void wfb_nee_gen(Params P, const float4 *__res
 #endif
             __syncthreads();  // s_cnt / s_base are reused by the next light
         }
-        if (act) {
-            Qshade.stu(U_RNG0, qi, rng.s0);
-            Qshade.stu(U_RNG1, qi, rng.s1);
-        }
+        // (the entry keeps the stream state from BEFORE these draws: wfb_shade repeats them)
     }
 }
 
@@ -552,16 +560,15 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
             F3 total = F3{0.0f, 0.0f, 0.0f};
             for (uint32_t li = 0; li < P.n_light; ++li) {
                 uint32_t o = P.light_off + li * LIGHT_F4;
-                float4 l0 = tbl.ld(o), l3 = tbl.ld(o + 3), l4 = tbl.ld(o + 4);
+                float4 l0 = tbl.ld(o), l1 = tbl.ld(o + 1), l2 = tbl.ld(o + 2), l3 = tbl.ld(o + 3), l4 = tbl.ld(o + 4);
                 F3 l[4];
                 float id2[4], tmax[4];
                 bool occ[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float *sp5 = samples + (size_t)(li * 4 + s) * 5 * cap + qi;
-                    l[s] = F3{sp5[0], sp5[cap], sp5[2 * cap]};
-                    tmax[s] = sp5[3 * cap];
-                    id2[s] = sp5[4 * cap];
+                for (int s = 0; s < 4; ++s) {  // the same draws as wfb_nee_gen made for the shadow rays
+                    float e1 = rng.gen() - 0.5f;
+                    float e2 = rng.gen() - 0.5f;
+                    light_sample(l0, l1, l2, x, e1, e2, l[s], tmax[s], id2[s]);
                     occ[s] = occ_sph[(size_t)(li * 4 + s) * cap + qi] != 0;
                 }
                 uint32_t c0 = 0, c1 = 0;
@@ -649,7 +656,7 @@ WfbLayout wfb_layout(uint32_t n, uint32_t n_light) {
     WfbLayout L;
     L.per_queue = al((size_t)n * 4 * (NF + NU));
     L.hits = al((size_t)n * 8);
-    L.samples = al((size_t)n * 4 * 5 * 4 * std::max(1u, n_light));
+    L.samples = al((size_t)n * 4 * 4 * 4 * std::max(1u, n_light));  // direction and distance limit of 4 samples per light
     L.occ = al((size_t)n * 4 * std::max(1u, n_light));
     L.list = al((size_t)n * 4 * 4 * std::max(1u, n_light));
     L.total = 4096 + 3 * L.per_queue + L.hits + L.samples + L.occ + L.list;
