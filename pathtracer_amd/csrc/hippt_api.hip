@@ -411,7 +411,7 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
             HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         }
-        const size_t need_slices = P.wf_streams_log2 ? ((size_t)pixels * 3 * sizeof(float)) << P.wf_streams_log2 : 0;
+        const size_t need_slices = use_bvh ? ((size_t)pixels * 3 * sizeof(float)) << P.wf_streams_log2 : 0;  // the streams' running sums
         if (need_slices > ctx->slice_bytes) {
             HIP_TRY(hipStreamSynchronize(st));
             if (ctx->slice_buf) HIP_TRY(hipFree(ctx->slice_buf));

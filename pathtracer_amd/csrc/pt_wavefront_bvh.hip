@@ -21,7 +21,8 @@
 //
 // SAMPLE STREAMS. A queue entry is a (pixel, stream) pair: the samples of a launch are cut into 2^k contiguous parts
 // per pixel (P.wf_streams_log2, chosen by the host so that up to 2^27 paths are in flight) and every part is a stream with
-// its own entry, its own running sum and its own slice of a partial-sum buffer, added up in a fixed order at the end.
+// its own entry and its own slice of a partial-sum buffer that holds its running sum; the slices are added up in a
+// fixed order at the end.
 // Why: a round is five dependent launches, and each traversal launch lasts at least as long as its LONGEST ray — a
 // ray that skims the sphere slab visits several hundred nodes at ~1 us per dependent visit, as long as the other two
 // million rays of a 1080p round take together. Measured with one stream per pixel: 160 / 364 / 495 / 562 Mpaths/s at
@@ -60,15 +61,13 @@ __device__ __forceinline__ void stream_range(const Params &P, uint32_t v, uint32
     begin = P.sample_begin + j * q + min(j, r);
     end = begin + q + (j < r ? 1u : 0u);
 }
-// where a finished stream leaves its sum: its slice of the partial-sum buffer (= accum itself with one stream)
-__device__ __forceinline__ void stream_store(const Params &P, float *__restrict__ out, uint32_t v, F3 sum) {
+// A stream's running sum lives in its slice of the partial-sum buffer (zeroed by the host before the launch), not in
+// the queue entries: only a vertex that receives light touches it (read-modify-write of 12 bytes; a stream has one
+// live entry at a time, so there is no race, and the additions happen in the same order as a carried sum's would).
+__device__ __forceinline__ void stream_add(const Params &P, float *__restrict__ out, uint32_t v, F3 c) {
     const uint32_t pix = v >> P.wf_streams_log2, j = v & ((1u << P.wf_streams_log2) - 1u);
     float *o = out + ((size_t)j * P.width * P.height + pix) * 3;
-    if (P.wf_streams_log2 == 0u) {
-        o[0] += sum.x, o[1] += sum.y, o[2] += sum.z;
-    } else {
-        o[0] = sum.x, o[1] = sum.y, o[2] = sum.z;
-    }
+    o[0] += c.x, o[1] += c.y, o[2] += c.z;
 }
 
 // renderer.rs:170-178: the pixel's next camera path
@@ -85,12 +84,11 @@ __device__ __forceinline__ void new_camera_path(const TblGlobal &tbl, const Para
     ++next;
 }
 
-__device__ __forceinline__ void push_ray(const WfQueue &Q, uint32_t pos, uint32_t pix, uint32_t depth, int media, uint32_t next, F3 sum,
+__device__ __forceinline__ void push_ray(const WfQueue &Q, uint32_t pos, uint32_t pix, uint32_t depth, int media, uint32_t next,
                                          F3 ro, F3 rd, F3 T, const Rng &rng) {
     Q.stu(U_PIX, pos, pix);
     Q.stu(U_META, pos, 1u | (depth << 1) | ((uint32_t)(media + 1) << 8));
     Q.stu(U_NEXT, pos, next);
-    Q.st3(F_SUM, pos, sum);
     Q.st3(F_RO, pos, ro);
     Q.st3(F_RD, pos, rd);
     Q.st3(F_T, pos, T);
@@ -131,7 +129,7 @@ __global__ __launch_bounds__(256) void wfb_init(Params P, const float4 *__restri
     Rng rng{0u, 1u};
     F3 ro, rd, T;
     new_camera_path(tbl, P, seed_mixed, v, next, rng, ro, rd, T, depth, media);
-    push_ray(Q, i, v, depth, media, next, F3{0, 0, 0}, ro, rd, T, rng);
+    push_ray(Q, i, v, depth, media, next, ro, rd, T, rng);
     if (i == 0) *Q.count = n;
 }
 
@@ -349,12 +347,11 @@ __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restr
         int media = -1;
         bool scatter = false;
         Rng rng{0u, 1u};
-        F3 ro = F3{0, 0, 0}, rd = F3{0, 0, 1}, T = F3{1, 1, 1}, sum = F3{0, 0, 0}, x = F3{0, 0, 0}, nn = F3{0, 1, 0};
+        F3 ro = F3{0, 0, 0}, rd = F3{0, 0, 1}, T = F3{1, 1, 1}, x = F3{0, 0, 0}, nn = F3{0, 1, 0};
         if (act) {
             pix = Qin.ldu(U_PIX, qi);
             uint32_t meta = Qin.ldu(U_META, qi);
             next = Qin.ldu(U_NEXT, qi);
-            sum = Qin.ld3(F_SUM, qi);
             depth = (meta >> 1) & 31u;
             media = (int)(meta >> 8) - 1;
             ro = Qin.ld3(F_RO, qi);
@@ -416,13 +413,12 @@ __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restr
                     new_camera_path(tbl, P, seed_mixed, pix, next, rng, ro, rd, T, depth, media);
                     alive = true;
                 }
-                to_next = alive;
-                if (!to_next) stream_store(P, accum, pix, sum);  // stream done: its sum goes to its slice
+                to_next = alive;  // (a finished stream's sum is already in its slice)
             }
         }
         uint32_t pn, ps;
         queue_reserve2(to_next, Qnext.count, pn, to_shade, Qshade.count, ps, s_cnt, s_base);
-        if (to_next) push_ray(Qnext, pn, pix, depth, media, next, sum, ro, rd, T, rng);
+        if (to_next) push_ray(Qnext, pn, pix, depth, media, next, ro, rd, T, rng);
         if (to_shade) {
             Qshade.stu(U_PIX, ps, pix);
             Qshade.stu(U_META, ps, 1u | (depth << 1) | (scatter ? 64u : 0u) | ((uint32_t)(media + 1) << 8));
@@ -430,7 +426,6 @@ __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restr
             Qshade.stu(U_MAT, ps, mat_word);
             Qshade.stu(U_RNG0, ps, rng.s0);
             Qshade.stu(U_RNG1, ps, rng.s1);
-            Qshade.st3(F_SUM, ps, sum);
             Qshade.st3(F_RD, ps, rd);
             Qshade.st3(F_T, ps, T);
             Qshade.st3(F_X, ps, x);
@@ -536,7 +531,7 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
         uint32_t pix = 0, next = 0, depth = 0;
         int media = -1;
         Rng rng{0u, 1u};
-        F3 ro = F3{0, 0, 0}, rd = F3{0, 0, 1}, T = F3{1, 1, 1}, sum = F3{0, 0, 0};
+        F3 ro = F3{0, 0, 0}, rd = F3{0, 0, 1}, T = F3{1, 1, 1};
         if (act) {
             pix = Qshade.ldu(U_PIX, qi);
             uint32_t meta = Qshade.ldu(U_META, qi);
@@ -552,7 +547,6 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
             F3 x = Qshade.ld3(F_X, qi), nn = Qshade.ld3(F_N, qi);
             rd = Qshade.ld3(F_RD, qi);
             T = Qshade.ld3(F_T, qi);
-            sum = Qshade.ld3(F_SUM, qi);
             Mat m = load_mat(tbl, P.mat_off, mid);
             ShadeK sk = make_shade(nn, -rd, m);
 
@@ -584,7 +578,8 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
                 }
                 total = madd(total, contrib, 0.25f);  // :82
             }
-            sum = sum + T * total;
+            const F3 gain = T * total;
+            if (gain.x != 0.0f || gain.y != 0.0f || gain.z != 0.0f) stream_add(P, accum, pix, gain);
 
             bool alive = true;
             if (scatter) {
@@ -630,11 +625,10 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
                 alive = true;
             }
             to_next = alive;
-            if (!to_next) stream_store(P, accum, pix, sum);
         }
         uint32_t pn, unused;
         queue_reserve2(to_next, Qnext.count, pn, false, nullptr, unused, s_cnt, s_base);
-        if (to_next) push_ray(Qnext, pn, pix, depth, media, next, sum, ro, rd, T, rng);
+        if (to_next) push_ray(Qnext, pn, pix, depth, media, next, ro, rd, T, rng);
     }
 }
 
@@ -679,7 +673,7 @@ uint32_t wfb_streams_log2(uint32_t n_pixels, uint32_t sample_count, uint32_t n_l
     return lg;
 }
 
-// P.wf_streams_log2 streams per pixel; `partial` = 2^that slices of width*height*3 floats (unused with one stream).
+// P.wf_streams_log2 streams per pixel; `partial` = 2^that slices of width*height*3 floats: the streams' running sums.
 //
 // TWO PIPELINES. With a second stream from the caller (`st2`) and at least two sample streams per pixel, the streams are
 // dealt to two groups, each with its own queues and counters, and the groups' rounds run concurrently: group 0 on `st`,
@@ -694,8 +688,8 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
                                 void *workspace, hipStream_t st, uint32_t *iterations_out, unsigned long long *stats, float *partial,
                                 hipStream_t st2, hipEvent_t ev_fork, hipEvent_t ev_join) {
     const uint32_t n_all = (P.width * P.height) << P.wf_streams_log2;
-    float *const sums = P.wf_streams_log2 ? partial : accum;
-    if (P.wf_streams_log2 && !partial) return hipErrorInvalidValue;
+    float *const sums = partial;
+    if (!partial) return hipErrorInvalidValue;
     const uint32_t group_bits = (WFB_GROUPS > 1 && st2 && ev_fork && ev_join && P.wf_streams_log2 >= 1u) ? 1u : 0u;
     const uint32_t n_groups = 1u << group_bits;
     const uint32_t n = n_all >> group_bits;
@@ -753,6 +747,8 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
         if ((e = hipFuncSetAttribute((const void *)WFB_TRAV<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
         if ((e = hipFuncSetAttribute((const void *)WFB_TRAV<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, b)) != hipSuccess) return e;
     }
+    const size_t image_floats = (size_t)P.width * P.height * 3;
+    if ((e = hipMemsetAsync(partial, 0, (image_floats * sizeof(float)) << P.wf_streams_log2, st)) != hipSuccess) return e;
     if (n_groups > 1) {
         if ((e = hipEventRecord(ev_fork, st)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(st2, ev_fork, 0)) != hipSuccess) return e;
@@ -821,9 +817,7 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
     }
     if (iterations_out) *iterations_out = it;
     if ((e = join(hipGetLastError())) != hipSuccess) return e;
-    if (P.wf_streams_log2) {
-        if ((e = launch_add_slices(accum, partial, 1u << P.wf_streams_log2, (size_t)P.width * P.height * 3, st)) != hipSuccess) return e;
-    }
+    if ((e = launch_add_slices(accum, partial, 1u << P.wf_streams_log2, image_floats, st)) != hipSuccess) return e;
     return hipGetLastError();
 }
 
