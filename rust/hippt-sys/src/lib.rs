@@ -28,6 +28,10 @@ pub struct hippt_scene {
 pub struct hippt_options { pub sample_begin: u32, pub sample_count: u32, pub max_depth: u32, pub seed: u32,
                            pub flags: u32, pub device: i32 }
 
+// hippt_options.flags (include/hippt.h)
+pub const HIPPT_FLAG_LOCAL_REDUCE: u32 = 128;     // *_multi: a device may appear several times, device add instead of ncclReduce
+pub const HIPPT_FLAG_TRAVERSAL_STATS: u32 = 256;  // LBVH pipeline: count node / leaf fetches (hippt_read_traversal_stats)
+
 extern "C" {
     pub fn hippt_last_error() -> *const c_char;
     pub fn hippt_render_rgba8(scene: *const hippt_scene, opts: *const hippt_options, out_rgba: *mut u8) -> c_int;
@@ -49,6 +53,16 @@ extern "C" {
                              out_rgba: *mut u8) -> c_int;
     pub fn hippt_checkpoint_save(path: *const c_char, accum: *const f32, width: u32, height: u32,
                                  samples_done: u32, seed: u32) -> c_int;
+    // device-resident rendering on a caller's HIP stream (accumulators in device memory), as bench.py drives it
+    pub fn hippt_render_accum_device(ctx: *mut hippt_context, opts: *const hippt_options, d_accum: *mut f32,
+                                     stream: *mut std::os::raw::c_void) -> c_int;
+    // the same for callers that cannot allocate (HIP graph capture, serving loops): table scenes, <= 4 194 304 pixels
+    pub fn hippt_render_accum_device_noalloc(ctx: *mut hippt_context, opts: *const hippt_options, d_accum: *mut f32,
+                                             stream: *mut std::os::raw::c_void) -> c_int;
+    pub fn hippt_resolve_device(ctx: *mut hippt_context, d_accum: *const f32, spp: u32, d_rgba: *mut u8,
+                                stream: *mut std::os::raw::c_void) -> c_int;
+    pub fn hippt_kernel_time_ms(ctx: *mut hippt_context, total_ms: *mut f64, launches: *mut u32) -> c_int;
+    pub fn hippt_read_traversal_stats(ctx: *mut hippt_context, stats10: *mut u64) -> c_int;
     pub fn hippt_checkpoint_load(path: *const c_char, accum: *mut f32, width: u32, height: u32,
                                  samples_done: *mut u32, seed: *mut u32) -> c_int;
 }
