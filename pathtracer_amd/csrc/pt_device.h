@@ -527,6 +527,24 @@ __device__ __forceinline__ F3 sample_ggx_h(F3 n, float roughness, float r1, floa
     return u * hx + v * hy + n * cos_theta;
 }
 // renderer.rs:330-335
+// Both surface lobes in one piece of code (renderer.rs:330-336 and ggx.rs:20-45 share the frame around n, the
+// azimuth and the combination; they differ in the polar angle and in what happens to the vector afterwards): a wave
+// whose lanes picked different lobes runs the common part once instead of twice. Same operations per lobe as
+// diffuse_dir / reflect(rd, sample_ggx_h()), hence the same bits.
+__device__ __forceinline__ F3 lobe_dir(bool diffuse, F3 n, F3 rd, float roughness, float ra, float rb) {
+    float cos_theta, sin_theta;
+    if (diffuse) {
+        sin_theta = fsqrt(rb);
+        cos_theta = fsqrt(1.0f - rb);
+    } else {
+        ggx_angles_exact(roughness, rb, cos_theta, sin_theta);
+    }
+    const float hx = cos2pi(ra) * sin_theta, hy = sin2pi(ra) * sin_theta;
+    const F3 u = normalize(any_orthonormal(n));
+    const F3 v = cross(n, u);
+    const F3 d = u * hx + v * hy + n * cos_theta;
+    return diffuse ? normalize(d) : reflect(rd, d);
+}
 __device__ __forceinline__ F3 diffuse_dir(F3 n, float u_phi, float r2) {
     F3 u = normalize(any_orthonormal(n));
     F3 v = cross(n, u);

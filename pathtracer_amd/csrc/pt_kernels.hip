@@ -181,18 +181,11 @@ __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x
                 bool cont = depth < 2u;
                 if (!cont) cont = rng.gen() < p;  // drawn only when depth >= 2 (:328)
                 if (cont) {
-                    F3 nd, f;
-                    if (rng.gen() < (1.0f - m.metallic)) {  // :329
-                        tr.bump(HIPPT_C_DIFFUSE_LOBES);
-                        float up = rng.gen(), r2 = rng.gen();
-                        nd = diffuse_dir(n, up, r2);
-                        f = m.color * 0.31830988618379067154f;
-                    } else {
-                        tr.bump(HIPPT_C_SPEC_LOBES);
-                        float r1 = rng.gen(), r2 = rng.gen();
-                        nd = reflect(rd, sample_ggx_h(n, m.roughness, r1, r2));
-                        f = F3{1.0f, 1.0f, 1.0f};
-                    }
+                    const bool diffuse = rng.gen() < (1.0f - m.metallic);  // :329
+                    tr.bump(diffuse ? HIPPT_C_DIFFUSE_LOBES : HIPPT_C_SPEC_LOBES);
+                    const float ra = rng.gen(), rb = rng.gen();  // (u_phi, r2) of :331-332 or (r1, r2) of ggx.rs:21-22
+                    const F3 nd = lobe_dir(diffuse, n, rd, m.roughness, ra, rb);
+                    const F3 f = diffuse ? m.color * 0.31830988618379067154f : F3{1.0f, 1.0f, 1.0f};
                     float c = dot(nd, n);
                     if (c > 0.0f) {  // :343
                         float w = depth >= 2u ? c * rcp(p) : c;
