@@ -20,7 +20,7 @@ namespace pt {
 //   * with t_c = c * slope + off the two faces of an axis are t_c -+ h * |slope|: three full-rate FMAs per axis
 //     instead of two FMAs plus a half-rate min and max to order the faces.
 // The centre is rounded to nearest (<= 1/4 node unit at the far ends of the root box, less towards its centre, i.e.
-// <= 0.6 % of the smaller root half-extents... exactly: half an ulp of a half float) and the half-size is rounded UP
+// exactly: half an ulp of a half float) and the half-size is rounded UP
 // after that error and the build / traversal rounding margins have been added to it (pt_bvh_build.hip: k_pack), so a
 // decoded box always contains the exact one: boxes may only prune.
 // child >= 0: internal node index; child < 0: leaf ~child = position in the
@@ -30,13 +30,15 @@ namespace pt {
 // child pointer with kBvhTopFlag set is a heap slot, any other pointer is a node of `nodes` (>= 0) or a leaf (< 0) as
 // before. Every lane of a traversal wave chases its own pointer, and 16-byte gathers cost the vector L1 about one
 // lane per clock and CU (tools/gather_microbench.hip: 0.43 lane-loads per clock per CU from a 3 MB table, 4.7 from
-// LDS). Measured on C4: 6 levels (63 nodes, 2 KB of LDS, 19 % of the node visits) +2.7 %; 8-10 levels
-// serve 28-38 % of the visits but their 8-32 KB cost resident waves, and the net is -3...-8 %.
+// LDS). Measured on C4: round 2 began with 6 levels (63 nodes, 2 KB of LDS per block, 19 % of the node
+// visits; +2.7 %) because more levels cost resident blocks; since the traversal stack keeps only what fits beside the
+// heap in LDS and spills the rest (pt_wavefront_bvh.hip), 8 levels (255 nodes, 8 KB, 24 % of the visits, 12 stack
+// entries in LDS) are worth another +1.2 %; 9+ levels leave too little stack.
 #ifndef PT_BVH_TOP_LEVELS
-#define PT_BVH_TOP_LEVELS 6
+#define PT_BVH_TOP_LEVELS 8
 #endif
 constexpr int kBvhTopLevels = PT_BVH_TOP_LEVELS;
-constexpr int kBvhTopSlots = (1 << kBvhTopLevels) - 1;  // 63 nodes, 2 016 bytes
+constexpr int kBvhTopSlots = (1 << kBvhTopLevels) - 1;  // 255 nodes, 8 160 bytes
 constexpr int kBvhTopFlag = 1 << 30;
 
 struct Bvh {

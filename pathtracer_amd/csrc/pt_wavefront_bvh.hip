@@ -163,8 +163,9 @@ __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q,
     uint32_t *stack = reinterpret_cast<uint32_t *>(s_top + 2 * kBvhTopSlots) + threadIdx.x;
     const uint32_t stride = kTravThreads;
     // Stack entries beyond the first lds_entries live in this thread's column of a global spill area. The host sizes the
-    // LDS part so that 8 blocks fit a CU (18 entries; 23 would allow 6) — on C4 no ray goes deeper than 17, so the
-    // spill path is there for correctness on deeper trees, not for speed (+3.5 % from the two extra blocks per CU).
+    // LDS part so that 8 blocks fit a CU beside the heap copy of the tree's first levels (12 entries with 8 levels; the
+    // 23 entries C4's tree could need would allow 3 blocks) — few rays defer more nodes than that, so the spill path
+    // costs little: +2 % from the extra blocks, +1.2 % from the two extra LDS levels.
     uint32_t *const spill_col = spill + (size_t)blockIdx.x * kTravThreads + threadIdx.x;
     const size_t spill_stride = (size_t)gridDim.x * kTravThreads;
     const uint32_t lane = threadIdx.x & 63u;
@@ -640,7 +641,7 @@ struct WfbLayout {
     size_t per_queue, hits, samples, occ, list, total;
 };
 constexpr unsigned kGridTrav = 256u * 8u * 256u / kTravThreads;  // persistent traversal blocks: every CU full
-constexpr uint32_t kLdsEntriesMax = (160u * 1024u / 8u - kBvhTopSlots * 32u) / (kTravThreads * 4u);  // 8 blocks per CU: 18
+constexpr uint32_t kLdsEntriesMax = (160u * 1024u / 8u - kBvhTopSlots * 32u) / (kTravThreads * 4u);  // 8 blocks per CU: 12 entries beside an 8-level heap
 // stack entries that do not fit the LDS part, one column per traversal thread, shared by all traversal launches of a stream
 size_t wfb_spill_bytes(uint32_t stack_entries) {
     return stack_entries > kLdsEntriesMax ? (size_t)(stack_entries - kLdsEntriesMax) * kGridTrav * kTravThreads * 4 : 256;
