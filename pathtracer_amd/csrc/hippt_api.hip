@@ -403,8 +403,19 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
             if (ctx->wf_ws) HIP_TRY(hipFree(ctx->wf_ws));
             ctx->wf_ws = nullptr;
             ctx->wf_ws_bytes = 0;
-            HIP_TRY(hipMalloc(&ctx->wf_ws, need));
+            // The LBVH queues are sized for throughput (up to 64 GiB of an otherwise empty 288 GB GPU). On a GPU that
+            // cannot spare that much, halve the number of sample streams until the queues fit: slower, same image.
+            hipError_t me = hipMalloc(&ctx->wf_ws, need);
+            while (me == hipErrorOutOfMemory && use_bvh && P.wf_streams_log2 > 0) {
+                (void)hipGetLastError();
+                --P.wf_streams_log2;
+                need = pt::wfb_workspace_bytes((uint32_t)pixels << P.wf_streams_log2, P.n_light);
+                me = hipMalloc(&ctx->wf_ws, need);
+            }
+            HIP_TRY(me);
             ctx->wf_ws_bytes = need;
+            if (std::getenv("HIPPT_DEBUG"))
+                std::fprintf(stderr, "[hippt] queue workspace %.2f GiB, %u sample streams per pixel\n", (double)need / (1ull << 30), 1u << P.wf_streams_log2);
         }
         if (use_bvh && !ctx->stream2) {
             HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));

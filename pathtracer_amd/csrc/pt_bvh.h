@@ -33,7 +33,7 @@ namespace pt {
 // LDS). Measured on C4: round 2 began with 6 levels (63 nodes, 2 KB of LDS per block, 19 % of the node
 // visits; +2.7 %) because more levels cost resident blocks; since the traversal stack keeps only what fits beside the
 // heap in LDS and spills the rest (pt_wavefront_bvh.hip), 8 levels (255 nodes, 8 KB, 24 % of the visits, 12 stack
-// entries in LDS) are worth another +1.2 %; 9+ levels leave too little stack.
+// entries in LDS) are worth another +1.2 %; 9 levels leave 4 stack entries: -12 %.
 #ifndef PT_BVH_TOP_LEVELS
 #define PT_BVH_TOP_LEVELS 8
 #endif

@@ -197,3 +197,24 @@ def test_traversal_stack_spills_to_global_memory(scene20k, monkeypatch):
     monkeypatch.setenv("HIPPT_WFB_LDS_STACK", "2")
     spilled = hip_renderer.render_accum(s, seed=7)
     assert ref.mean() > 0 and np.array_equal(ref, spilled)
+
+
+def test_queue_allocation_falls_back_to_fewer_streams_when_memory_is_short(scene20k, monkeypatch, capfd):
+    """The LBVH pipeline sizes its queues for throughput (here 2^26 entries, ~26 GB, for a 64-spp launch at 1080p). With
+    only 16 GiB of the GPU free the allocation fails and the library halves the number of sample streams until the
+    queues fit: same image up to the order in which the streams' sums are added."""
+    import torch
+    from pathtracer_amd import hip_renderer
+    s = scene20k.with_render(1920, 1080, 64)
+    ref = hip_renderer.render_accum(s, seed=9)
+    free, _total = torch.cuda.mem_get_info(0)
+    hog = torch.empty(free - (16 << 30), dtype=torch.uint8, device="cuda")
+    monkeypatch.setenv("HIPPT_DEBUG", "1")
+    try:
+        got = hip_renderer.render_accum(s, seed=9)
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    assert ref.mean() > 0 and np.allclose(got, ref, rtol=2e-5, atol=1e-4)
+    log = capfd.readouterr().err          # the library reports the queues it ended up with
+    assert "16 sample streams per pixel" in log, log
