@@ -112,6 +112,45 @@ def test_loader_rejects_malformed_json_and_missing_file():
     assert "scene file" in str(e.value)                     # scene.rs:95 expect("scene file")
 
 
+def test_loader_survives_mutated_scene_files():
+    """4 000 random mutations of scene.example.json (deleted spans, inserted tokens, random bytes, truncation, duplicated
+    spans, extreme numbers) and million-deep nesting: the loader either returns a scene or an error, never crashes or
+    hangs. (The same mutator ran 30 000 cases under ASan + UBSan against host_scene.cpp alone: clean.)"""
+    import random
+    from pathtracer_amd import HipptError, Scene
+    rnd = random.Random(12345)
+    base = open(os.path.join(ROOT, "scenes", "scene.example.json"), "rb").read()
+    tokens = [b"{", b"}", b"[", b"]", b",", b":", b'"', b"null", b"true", b"-", b"1e999", b"1e-999", b"NaN", b"\\u00", b"\\",
+              b"0.", b"-0", b"99999999999999999999", b'"Sphere"', b'"Plane"', b'"material"', b'"objects"']
+    ok = bad = 0
+    for _ in range(4000):
+        s = bytearray(base)
+        for _m in range(rnd.randint(1, 4)):
+            pos = rnd.randrange(len(s) + 1)
+            kind = rnd.randrange(5)
+            if kind == 0 and s:
+                del s[pos % len(s):pos % len(s) + rnd.randint(1, 8)]
+            elif kind == 1:
+                s[pos:pos] = rnd.choice(tokens)
+            elif kind == 2 and s:
+                s[pos % len(s)] = rnd.randrange(256)
+            elif kind == 3:
+                del s[pos:]
+            elif s:
+                a = rnd.randrange(len(s))
+                s[pos:pos] = s[a:a + rnd.randrange(64)]
+        try:
+            sc = Scene.parse(bytes(s))
+            assert sc.width > 0 and sc.height > 0
+            ok += 1
+        except HipptError:
+            bad += 1
+    assert ok > 50 and bad > 2000, (ok, bad)
+    for opener in (b"[", b'{"a":', b'{"camera":['):
+        with pytest.raises(HipptError, match="nesting too deep"):
+            Scene.parse(opener * 1000000)
+
+
 def test_json_string_escapes_and_numbers():
     from pathtracer_amd import Scene
     d = json.loads(json.dumps(MINI))
