@@ -354,6 +354,9 @@ def main():
                     r[k] = pmc_pending[k]
             if "note" in pmc_pending:
                 r["pmc_note"] = pmc_pending["note"]
+            if r.get("bound") == "l2" and r.get("traffic"):  # north star: "for wavefront queues, achieved HBM GB/s is also reported"
+                r["hbm_gbs"] = round(r["traffic"] / (r["kernel_ms"] * r["launches_per_step"] * 1e-3) / 1e9, 1)
+                r["hbm_frac"] = round(r["hbm_gbs"] / 8000.0, 4)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: the other ranks would wait at the barrier
             out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
     if world > 1:
