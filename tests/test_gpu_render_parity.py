@@ -171,3 +171,29 @@ def test_wavefront_variant_matches_megakernel(oracle):
     parts = (hip_renderer.render_accum(s, 0, 3, seed=1, flags=_abi.FLAG_WAVEFRONT)
              + hip_renderer.render_accum(s, 3, 7, seed=1, flags=_abi.FLAG_WAVEFRONT))
     assert np.allclose(full, parts, rtol=2e-6, atol=1e-6)
+
+
+def test_independent_seeds_agree_at_the_noise_floor(oracle):
+    """BASELINE north star, statistical form: GPU and CPU images from DIFFERENT random streams agree in mean radiance
+    (within 1 %) and differ per pixel by what Monte-Carlo noise predicts — the RMS of (gpu - cpu) / sigma is 1, where
+    sigma^2 is the sum of the two images' per-pixel variances of the mean, estimated from 16 batches of 32 samples.
+    (The same-seed tests above compare sample for sample; this one would also catch an error common to both sides'
+    use of the shared stream, such as correlated draws.)"""
+    from pathtracer_amd import Scene, hip_renderer
+    for name, mean_tol in (("scene.example.json", 1e-2), ("glass_fog.json", 1e-2)):
+        s = Scene.load(os.path.join(ROOT, "scenes", name), 160, 120, 512)
+        s.materials["roughness"] = np.maximum(s.materials["roughness"], 0.2)   # no roughness-0.01 fireflies in a variance estimate
+        nb, per = 16, 32
+        g = np.stack([hip_renderer.render_accum(s, b * per, per, seed=101).astype(np.float64) / per for b in range(nb)])
+        c = np.stack([oracle.render_accum(s, b * per, per, seed=202).astype(np.float64) / per for b in range(nb)])
+        mg, mc = g.mean(axis=0), c.mean(axis=0)
+        tot_g, tot_c = mg.sum(), mc.sum()
+        assert abs(tot_g - tot_c) <= mean_tol * tot_c, (name, tot_g, tot_c)
+        var = g.var(axis=0, ddof=1) / nb + c.var(axis=0, ddof=1) / nb
+        lit = var > 1e-12
+        z = (mg - mc)[lit] / np.sqrt(var[lit])
+        # Student-like tails (variance from 16 batches): compare the central 98 % with what a unit normal gives (0.93)
+        zc = z[np.abs(z) < np.quantile(np.abs(z), 0.98)]
+        rms = float(np.sqrt((zc ** 2).mean()))
+        assert 0.8 < rms < 1.15, (name, rms)
+        assert abs(float(np.median(z))) < 0.05, (name, float(np.median(z)))      # no systematic offset
