@@ -318,12 +318,13 @@ def main():
             # nodes of the tree's first levels come from the block's LDS copy: not memory traffic
             trav = sum((ts[k]["nodes"] - ts[k]["nodes_from_lds"]) * 32 + ts[k]["leaf_fetches"] * 32 + ts[k]["aux_rows"] * 16
                        for k in ("closest", "any"))
-            rays_io = ts["closest"]["rays"] * (24 + 8) + ts["any"]["rays"] * (4 + 4 + 16 + 12 + 1)
-            # per extend ray: ray entry + hit record in (56 + 8), next entry out (56); per NEE vertex: shade entry out (72), sampling reads
-            # x, n and the stream state (32) and writes direction + distance limit + occlusion preset of 4 L samples (68 L),
-            # shading reads the entry and the occlusion bytes (72 + 4 L) and regenerates the samples from the stream state
+            # closest ray: origin + direction in, hit record out; shadow rays: the traversal kernel reads a vertex's point, normal
+            # and stream state once (32 B, its 4 L samples are neighbouring lanes) and writes one occlusion byte per sample
+            rays_io = ts["closest"]["rays"] * (24 + 8) + V * (32 + 4 * L)
+            # per extend ray: ray entry + hit record in (56 + 8), next entry out (56); per NEE vertex: shade entry out (72),
+            # back in with its occlusion bytes for shading (72 + 4 L), which regenerates the samples from the stream state
             # (the streams' running sums live in their slices: 12 B read + written only where a vertex receives light, not counted)
-            queues = E * (64 + 56) + V * (72 + 32 + L * 68 + 72 + L * 4)
+            queues = E * (64 + 56) + V * (72 + 72 + L * 4)
             step_bytes = trav + rays_io + queues
             gbs = step_bytes / (k_ms * launches_per_step * 1e-3) / 1e9
             out["roofline"] = {

@@ -391,11 +391,11 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
         return hippt_set_error(HIPPT_ERR_INVALID, "HIPPT_FLAG_WAVEFRONT and HIPPT_FLAG_MEGAKERNEL are exclusive");
     // LBVH scenes default to the queue pipeline with persistent traversal kernels (2.4x the BVH megakernel on the
     // 100 000-sphere scene); the counting variant exists only as a megakernel
-    if (use_bvh && !(o.flags & HIPPT_FLAG_MEGAKERNEL) && !count && P.n_mat <= 0xffffu && P.max_depth <= 31u) wavefront = true;
+    if (use_bvh && !(o.flags & HIPPT_FLAG_MEGAKERNEL) && !count && P.n_mat <= 0xffffu && P.max_depth <= 31u && P.n_light <= 96u) wavefront = true;
     if (wavefront) {
-        if ((!use_bvh && !lds) || count || P.n_mat > 0xffffu || P.max_depth > 31u)
+        if ((!use_bvh && !lds) || count || P.n_mat > 0xffffu || P.max_depth > 31u || (use_bvh && P.n_light > 96u))
             return hippt_set_error(HIPPT_ERR_INVALID, "the wavefront variants support LDS-sized scenes or LBVH scenes, no counters, "
-                                                      "<= 65535 materials and max_depth <= 31");
+                                                      "<= 65535 materials, max_depth <= 31 and (LBVH scenes) <= 96 lights");
         // LBVH pipeline: several sample streams per pixel (pt_wavefront_bvh.hip), sized for the largest chunk of this call
         const uint64_t per_chunk = std::max<uint64_t>(1, kPathsPerLaunch / pixels);
         if (use_bvh && !(o.flags & HIPPT_FLAG_NO_SLICES))

@@ -13,9 +13,9 @@
 //   wfb_logic           : planes + winner refinement (pt_device.h: refine_hit), medium free flight,
 //                         classification; glass / miss handled here; opaque / scatter vertices go to the
 //                         shade queue; a finished path is replaced by the pixel's next camera path
-//   wfb_nee_gen         : draws the 4 L light samples of every shade-queue entry (renderer.rs:35-46)
-//                         and writes them as shadow rays
-//   wfb_traverse<true>  : any sphere hit for every shadow ray
+//   wfb_traverse<true>  : any sphere hit for the 4 L light samples of every shade-queue entry (renderer.rs:35-46):
+//                         the lane that takes a sample regenerates it from the entry's stream state, drops it if
+//                         it faces away, traces it otherwise (there is no sampling kernel and no ray list)
 //   wfb_shade           : plane occlusion, BRDF evaluation (renderer.rs:49-82), Russian roulette, lobe
 //                         sampling (renderer.rs:323-349) or phase-function scatter (:269-286)
 //
@@ -43,9 +43,6 @@ namespace {
 
 #ifndef WFB_FETCH_MIN
 #define WFB_FETCH_MIN 16
-#endif
-#ifndef WFB_LIST_VERTEX_MAJOR
-#define WFB_LIST_VERTEX_MAJOR 1  // shadow-ray list order: the samples of one vertex are neighbours (+5.3 % on C4: neighbouring lanes share node lines)
 #endif
 #ifndef WFB_ANY_NEAR_FIRST
 #define WFB_ANY_NEAR_FIRST 1  // +1.8 % on C4 with the vertex-major list (was -1 % with the sample-major one)
@@ -99,8 +96,8 @@ __device__ __forceinline__ void push_ray(const WfQueue &Q, uint32_t pos, uint32_
 }  // namespace
 
 // One light sample of renderer.rs:35-44 from its two uniforms: unit direction, distance limit of the shadow ray
-// (|lvec| sqrt(0.999), renderer.rs:46) and 1 / dist^2. wfb_nee_gen (for the shadow rays) and wfb_shade (for the
-// evaluation) both call it with the same uniforms instead of passing 20 bytes per sample through HBM; the operations
+// (|lvec| sqrt(0.999), renderer.rs:46) and 1 / dist^2. wfb_traverse<ANY> (for the shadow rays) and wfb_shade (for the
+// evaluation) both call it with the same uniforms instead of passing the samples through HBM; the operations
 // are spelt out so that both kernels round alike.
 __device__ __forceinline__ void light_sample(float4 l0, float4 l1, float4 l2, F3 x, float e1, float e2, F3 &l, float &tmax, float &inv_d2) {
     const F3 lvec = F3{fmaf(l2.x, e2, fmaf(l1.x, e1, l0.x)) - x.x, fmaf(l2.y, e2, fmaf(l1.y, e1, l0.y)) - x.y,
@@ -134,9 +131,10 @@ __global__ __launch_bounds__(256) void wfb_init(Params P, const float4 *__restri
 }
 
 // Persistent LBVH traversal over a ray array. ANY = false: closest sphere of ray i = entry i of Q
-// (same result as pt_bvh.h: bvh_closest); out: hit_t[i], hit_leaf[i] (-1: none). ANY = true: shadow ray r
-// is sample k of shade-queue entry e with ray_list[r] = k * cap + e (origin Q.F_X[e] + 1e-4 l, direction l
-// and tmax from the sample planes); out: occ[k * cap + e] (same result as bvh_any).
+// (same result as pt_bvh.h: bvh_closest); out: hit_t[i], hit_leaf[i] (-1: none). ANY = true: shadow ray r is light
+// sample k = r % 4L of shade-queue entry e = r / 4L — vertex-major, so the samples of one vertex are neighbouring lanes
+// that walk the same nodes (+5.3 % on C4 over a sample-major order) — origin Q.F_X[e] + 1e-4 l, direction l and tmax
+// from light_sample(); out: occ[k * cap + e] (same result as bvh_any; 1 also for samples that need no ray).
 // STATS: also counts what the rays fetch (stats[0..3] = rays, nodes visited (32 B each), leaf fetches (two spheres,
 // 32 B, each), aux rows (16 B)), wave-reduced, for the memory roofline of bench.py --config c4.
 #ifndef WFB_INFLIGHT_LOG2
@@ -150,12 +148,13 @@ __global__ __launch_bounds__(256) void wfb_init(Params P, const float4 *__restri
 #endif
 constexpr uint32_t kTravThreads = WFB_TRAV_THREADS;  // traversal blocks: one LDS copy of the tree's top per 8 waves
 template <bool ANY, bool STATS = false>
-__global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q, const float *__restrict__ samples,
-                                                    const uint32_t *__restrict__ ray_list, const uint32_t *__restrict__ ray_count,
+__global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q, const float4 *__restrict__ blob,
+                                                    const uint32_t *__restrict__ jump,
                                                     uint32_t *__restrict__ head,
                                                     float *__restrict__ hit_t, int *__restrict__ hit_leaf,
                                                     uint8_t *__restrict__ occ_out, unsigned long long *__restrict__ stats,
-                                                    uint32_t lds_entries, uint32_t *__restrict__ spill) {
+                                                    uint32_t lds_entries, uint32_t *__restrict__ spill, uint32_t light_off = 0,
+                                                    uint32_t n_light = 0) {
     uint32_t st_rays = 0, st_nodes = 0, st_leaves = 0, st_aux = 0, st_top = 0;
     extern __shared__ uint4 s_top[];  // the tree's first levels (kBvhTopSlots x 2 uint4), then stack_entries x kTravThreads words
     for (uint32_t i = threadIdx.x; i < 2u * kBvhTopSlots; i += kTravThreads) s_top[i] = bvh.top[i];
@@ -169,7 +168,14 @@ __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q,
     uint32_t *const spill_col = spill + (size_t)blockIdx.x * kTravThreads + threadIdx.x;
     const size_t spill_stride = (size_t)gridDim.x * kTravThreads;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_rays = ANY ? *ray_count : *Q.count;
+    // ANY: the "rays" are the 4 L light samples of every shade-queue entry, vertex-major (sample k of entry e is ray
+    // e * 4 L + k): a lane that takes one regenerates the sample from the entry's stream state (LCG jump-ahead by 2 k
+    // draws, table `jump` = {a^(2k), 1 + a + ... + a^(2k-1)}), drops it if it faces away from the surface or the
+    // light (renderer.rs:49: no shadow ray needed, occlusion byte 1) and otherwise traces it. There is no sampling
+    // kernel, no sample buffer and no ray list.
+    const uint32_t n4 = 4u * n_light;
+    const uint32_t n4_shift = (n4 & (n4 - 1u)) == 0u ? (uint32_t)__builtin_ctz(n4 | 0x80000000u) : 0xffffffffu;
+    const uint32_t n_rays = ANY ? *Q.count * n4 : *Q.count;
     const size_t cap = Q.cap;
 
     uint32_t w_next = 0, w_end = 0;  // this wave's reserved range of ray indices (wave-uniform)
@@ -203,17 +209,26 @@ __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q,
                 uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 if (!has && rank < avail) {
                     uint32_t ridx = w_next + rank;
+                    bool take = true;
                     if (ANY) {
-                        uint32_t ke = ray_list[ridx];  // sample k of shade-queue entry e, as k * cap + e
-                        uint32_t k = ke / (uint32_t)cap, e = ke - k * (uint32_t)cap;
-                        const float *sp5 = samples + (size_t)k * 4 * cap + e;
-                        F3 l = F3{sp5[0], sp5[cap], sp5[2 * cap]};
-                        float tmax = sp5[3 * cap];
-                        F3 x = Q.ld3(F_X, e);
+                        const uint32_t e = n4_shift != 0xffffffffu ? ridx >> n4_shift : ridx / n4, k = ridx - e * n4;
+                        const float4 *lrow = blob + light_off + (k >> 2) * LIGHT_F4;
+                        const float4 l0 = lrow[0], l1 = lrow[1], l2 = lrow[2], l4 = lrow[4];
+                        const uint32_t ja = jump[2u * k], jc = jump[2u * k + 1u];
+                        const uint32_t s0 = Q.ldu(U_RNG0, e), inc = Q.ldu(U_RNG1, e);
+                        Rng rg{s0 * ja + inc * jc, inc};
+                        const float e1 = rg.gen() - 0.5f;
+                        const float e2 = rg.gen() - 0.5f;
+                        const F3 x = Q.ld3(F_X, e), nn = Q.ld3(F_N, e);
+                        F3 l;
+                        float tmax, inv_d2;
+                        light_sample(l0, l1, l2, x, e1, e2, l, tmax, inv_d2);
+                        out_idx = k * (uint32_t)cap + e;
+                        take = (dot(nn, l) > 0.0f) & (-dot(l, f3(l4)) > 0.0f);
+                        if (!take) occ_out[out_idx] = 1;
                         r = make_ray(madd(x, l, 1e-4f), l);
                         lim = tmax * tmax;
                         t_max = fsqrt(lim) * 1.000001f;
-                        out_idx = ke;
                     } else {
                         r = make_ray(Q.ld3(F_RO, ridx), Q.ld3(F_RD, ridx));
                         best_t = __builtin_inff();
@@ -221,11 +236,13 @@ __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q,
                         best_ord = 0xffffffffu;
                         out_idx = ridx;
                     }
-                    br = make_box_ray(bvh, r.ro, r.rd);
-                    node = kBvhTopFlag;  // the root, in LDS
-                    sp = 0;
-                    has = true;
-                    if (STATS) ++st_rays;
+                    if (take) {
+                        br = make_box_ray(bvh, r.ro, r.rd);
+                        node = kBvhTopFlag;  // the root, in LDS
+                        sp = 0;
+                        has = true;
+                        if (STATS) ++st_rays;
+                    }
                 }
                 w_next += min(n_idle, avail);
             } else if (n_idle == 64u) {
@@ -435,90 +452,8 @@ __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restr
     }
 }
 
-// renderer.rs:35-46 for every entry of the shade queue: the 4 samples of every light, in the draw order of
-// pt_trace.h: direct_light. Sample k = light * 4 + s, five planes each: l.x, l.y, l.z, tmax, 1 / dist2.
-// A sample that faces away (n.l <= 0 or the light's back side, renderer.rs:50,55) contributes nothing
-// whether it is occluded or not, so it gets no shadow ray: its occlusion byte is preset to 1, and only the
-// other samples are appended to the shadow-ray list.
-__global__ __launch_bounds__(256) void wfb_nee_gen(Params P, const float4 *__restrict__ blob, WfQueue Qshade,
-                                                   float *__restrict__ samples, uint8_t *__restrict__ occ,
-                                                   uint32_t *__restrict__ ray_list, uint32_t *__restrict__ ray_count) {
-    __shared__ uint32_t s_cnt[2][4], s_base[2];
-    TblGlobal tbl{blob};
-    const uint32_t count = *Qshade.count;
-    const size_t cap = Qshade.cap;
-    for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
-        const uint32_t qi = base + threadIdx.x;
-        const bool act = qi < count;
-        Rng rng{0u, 1u};
-        F3 x = F3{0, 0, 0}, nn = F3{0, 1, 0};
-        if (act) {
-            rng = Rng{Qshade.ldu(U_RNG0, qi), Qshade.ldu(U_RNG1, qi)};
-            x = Qshade.ld3(F_X, qi);
-            nn = Qshade.ld3(F_N, qi);
-        }
-        for (uint32_t li = 0; li < P.n_light; ++li) {
-            uint32_t o = P.light_off + li * LIGHT_F4;
-            float4 l0 = tbl.ld(o), l1 = tbl.ld(o + 1), l2 = tbl.ld(o + 2), l4 = tbl.ld(o + 4);
-            bool want[4] = {false, false, false, false};
-#pragma unroll
-            for (uint32_t s = 0; s < 4; ++s) {
-                const uint32_t k = li * 4 + s;
-                if (act) {
-                    float e1 = rng.gen() - 0.5f;
-                    float e2 = rng.gen() - 0.5f;
-                    F3 l;
-                    float tmax, inv_d2;
-                    light_sample(l0, l1, l2, x, e1, e2, l, tmax, inv_d2);
-                    float *sp5 = samples + (size_t)k * 4 * cap + qi;
-                    sp5[0] = l.x;
-                    sp5[cap] = l.y;
-                    sp5[2 * cap] = l.z;
-                    sp5[3 * cap] = tmax;
-                    want[s] = (dot(nn, l) > 0.0f) & (-dot(l, f3(l4)) > 0.0f);
-                    if (!want[s]) occ[(size_t)k * cap + qi] = 1;
-                }
-            }
-            // one reservation per block and light for the 4 samples: list order (wave, sample, lane)
-            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-            const unsigned long long below = (1ull << lane) - 1ull;
-            unsigned long long m[4];
-            uint32_t wave_tot = 0;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                m[s] = __ballot(want[s]);
-                wave_tot += (uint32_t)__popcll(m[s]);
-            }
-            if (lane == 0) s_cnt[0][wave] = wave_tot;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                uint32_t tot = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
-                s_base[0] = tot ? atomicAdd(ray_count, tot) : 0u;
-            }
-            __syncthreads();
-            uint32_t off = s_base[0];
-            for (uint32_t w = 0; w < wave; ++w) off += s_cnt[0][w];
-#if WFB_LIST_VERTEX_MAJOR
-#pragma unroll
-            for (uint32_t s = 0; s < 4; ++s) off += (uint32_t)__popcll(m[s] & below);
-#pragma unroll
-            for (uint32_t s = 0; s < 4; ++s)
-                if (want[s]) ray_list[off++] = (li * 4 + s) * (uint32_t)cap + qi;
-#else
-#pragma unroll
-            for (uint32_t s = 0; s < 4; ++s) {
-                if (want[s]) ray_list[off + (uint32_t)__popcll(m[s] & below)] = (li * 4 + s) * (uint32_t)cap + qi;
-                off += (uint32_t)__popcll(m[s]);
-            }
-#endif
-            __syncthreads();  // s_cnt / s_base are reused by the next light
-        }
-        // (the entry keeps the stream state from BEFORE these draws: wfb_shade repeats them)
-    }
-}
-
 __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restrict__ blob, WfQueue Qshade,
-                                                 const float *__restrict__ samples, const uint8_t *__restrict__ occ_sph,
+                                                 const uint8_t *__restrict__ occ_sph,
                                                  WfQueue Qnext, float *__restrict__ accum) {
     __shared__ uint32_t s_cnt[2][4], s_base[2];
     TblGlobal tbl{blob};
@@ -560,7 +495,7 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
                 float id2[4], tmax[4];
                 bool occ[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {  // the same draws as wfb_nee_gen made for the shadow rays
+                for (int s = 0; s < 4; ++s) {  // the same draws as wfb_traverse<ANY> made for the shadow rays
                     float e1 = rng.gen() - 0.5f;
                     float e2 = rng.gen() - 0.5f;
                     light_sample(l0, l1, l2, x, e1, e2, l[s], tmax[s], id2[s]);
@@ -638,7 +573,7 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
 // ---- host driver -----------------------------------------------------------------------
 namespace {
 struct WfbLayout {
-    size_t per_queue, hits, samples, occ, list, total;
+    size_t per_queue, hits, occ, total;
 };
 constexpr unsigned kGridTrav = 256u * 8u * 256u / kTravThreads;  // persistent traversal blocks: every CU full
 constexpr uint32_t kLdsEntriesMax = (160u * 1024u / 8u - kBvhTopSlots * 32u) / (kTravThreads * 4u);  // 8 blocks per CU: 12 entries beside an 8-level heap
@@ -651,10 +586,8 @@ WfbLayout wfb_layout(uint32_t n, uint32_t n_light) {
     WfbLayout L;
     L.per_queue = al((size_t)n * 4 * (NF + NU));
     L.hits = al((size_t)n * 8);
-    L.samples = al((size_t)n * 4 * 4 * 4 * std::max(1u, n_light));  // direction and distance limit of 4 samples per light
     L.occ = al((size_t)n * 4 * std::max(1u, n_light));
-    L.list = al((size_t)n * 4 * 4 * std::max(1u, n_light));
-    L.total = 4096 + 3 * L.per_queue + L.hits + L.samples + L.occ + L.list;
+    L.total = 4096 + 3 * L.per_queue + L.hits + L.occ;
     return L;
 }
 }  // namespace
@@ -697,12 +630,12 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
     const WfbLayout L = wfb_layout(n, P.n_light);
     struct Group {
         hipStream_t st;
-        uint32_t *counters;  // [0],[1]: ray queue counts (ping-pong), [2]: shade count, [3],[4]: fetch heads, [5]: shadow-ray count
+        uint32_t *counters;  // [0],[1]: ray queue counts (ping-pong), [2]: shade count, [3],[4]: fetch heads; [256..]: the jump table
         WfQueue Q[3];
-        float *hit_t, *samples;
+        float *hit_t;
         int *hit_leaf;
         uint8_t *occ;
-        uint32_t *ray_list, *spill;
+        uint32_t *spill;
         bool done;
     } G[2];
     uint32_t lds_entries = std::min(stack_entries, kLdsEntriesMax);
@@ -727,11 +660,7 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
         G[g].hit_t = (float *)w;
         G[g].hit_leaf = (int *)(w + (size_t)n * 4);
         w += L.hits;
-        G[g].samples = (float *)w;
-        w += L.samples;
         G[g].occ = w;
-        w += L.occ;
-        G[g].ray_list = (uint32_t *)w;
         G[g].done = false;
     }
 
@@ -763,8 +692,20 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
         }
         return err;
     };
+    // LCG jump-ahead constants of the light samples (wfb_traverse<ANY>): after j draws the state is A_j s + C_j inc
+    uint32_t jump[2 * 4 * 96];
+    const uint32_t n4 = 4u * P.n_light;
+    if (n4 > 4u * 96u) return join(hipErrorInvalidValue);  // (the API keeps scenes with more lights off this pipeline)
+    {
+        uint32_t A = 1u, C = 0u;
+        for (uint32_t k = 0; k < n4; ++k) {
+            jump[2 * k] = A, jump[2 * k + 1] = C;
+            for (int d = 0; d < 2; ++d) C = C * 2891336453u + 1u, A *= 2891336453u;
+        }
+    }
     for (uint32_t g = 0; g < n_groups; ++g) {
         if ((e = hipMemsetAsync(G[g].counters, 0, 4096, G[g].st)) != hipSuccess) return join(e);
+        if (n4 && (e = hipMemcpyAsync(G[g].counters + 256, jump, (size_t)n4 * 8, hipMemcpyHostToDevice, G[g].st)) != hipSuccess) return join(e);
         hipLaunchKernelGGL(wfb_init, dim3(blocks_all), dim3(256), 0, G[g].st, P, blob, G[g].Q[0], n, group_bits, g);
     }
     const uint32_t max_iter = ((P.sample_count >> P.wf_streams_log2) + 1u) * P.max_depth + 1;
@@ -777,25 +718,25 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
             hipStream_t s = A.st;
             uint32_t *counters = A.counters;
             if ((e = hipMemsetAsync(&counters[1 - cur], 0, 4, s)) != hipSuccess) return join(e);
-            if ((e = hipMemsetAsync(&counters[2], 0, 16, s)) != hipSuccess) return join(e);  // shade count, both fetch heads, shadow-ray count
+            if ((e = hipMemsetAsync(&counters[2], 0, 16, s)) != hipSuccess) return join(e);  // shade count, both fetch heads
             if (stats)
-                hipLaunchKernelGGL((WFB_TRAV<false, true>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[cur], (const float *)nullptr,
-                                   (const uint32_t *)nullptr, (const uint32_t *)nullptr, &counters[3], A.hit_t, A.hit_leaf, (uint8_t *)nullptr, stats, lds_entries, A.spill);
+                hipLaunchKernelGGL((WFB_TRAV<false, true>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[cur], (const float4 *)nullptr,
+                                   (const uint32_t *)nullptr, &counters[3], A.hit_t, A.hit_leaf, (uint8_t *)nullptr, stats, lds_entries, A.spill);
             else
-                hipLaunchKernelGGL((WFB_TRAV<false, false>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[cur], (const float *)nullptr,
-                                   (const uint32_t *)nullptr, (const uint32_t *)nullptr, &counters[3], A.hit_t, A.hit_leaf, (uint8_t *)nullptr,
+                hipLaunchKernelGGL((WFB_TRAV<false, false>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[cur], (const float4 *)nullptr,
+                                   (const uint32_t *)nullptr, &counters[3], A.hit_t, A.hit_leaf, (uint8_t *)nullptr,
                                    (unsigned long long *)nullptr, lds_entries, A.spill);
             hipLaunchKernelGGL(wfb_logic, dim3(grid), dim3(256), 0, s, P, blob, bvh, A.Q[cur], (const float *)A.hit_t,
                                (const int *)A.hit_leaf, A.Q[1 - cur], A.Q[2], sums);
-            hipLaunchKernelGGL(wfb_nee_gen, dim3(grid), dim3(256), 0, s, P, blob, A.Q[2], A.samples, A.occ, A.ray_list, &counters[5]);
             if (stats)
-                hipLaunchKernelGGL((WFB_TRAV<true, true>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[2], (const float *)A.samples,
-                                   (const uint32_t *)A.ray_list, (const uint32_t *)&counters[5], &counters[4], (float *)nullptr, (int *)nullptr, A.occ, stats, lds_entries, A.spill);
+                hipLaunchKernelGGL((WFB_TRAV<true, true>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[2], blob,
+                                   (const uint32_t *)(counters + 256), &counters[4], (float *)nullptr, (int *)nullptr, A.occ,
+                                   stats, lds_entries, A.spill, P.light_off, P.n_light);
             else
-                hipLaunchKernelGGL((WFB_TRAV<true, false>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[2], (const float *)A.samples,
-                                   (const uint32_t *)A.ray_list, (const uint32_t *)&counters[5], &counters[4], (float *)nullptr, (int *)nullptr, A.occ,
-                                   (unsigned long long *)nullptr, lds_entries, A.spill);
-            hipLaunchKernelGGL(wfb_shade, dim3(grid), dim3(256), 0, s, P, blob, A.Q[2], (const float *)A.samples, (const uint8_t *)A.occ,
+                hipLaunchKernelGGL((WFB_TRAV<true, false>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[2], blob,
+                                   (const uint32_t *)(counters + 256), &counters[4], (float *)nullptr, (int *)nullptr, A.occ,
+                                   (unsigned long long *)nullptr, lds_entries, A.spill, P.light_off, P.n_light);
+            hipLaunchKernelGGL(wfb_shade, dim3(grid), dim3(256), 0, s, P, blob, A.Q[2], (const uint8_t *)A.occ,
                                A.Q[1 - cur], sums);
         }
         cur = 1 - cur;
