@@ -339,7 +339,7 @@ def main():
                             for k in ("closest", "any")},
                 "valu_fp32": {"achieved_tflops": round(achieved, 3), "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4)},
                 "note": "rank 0's GPU: algorithmic bytes of a step (32 B per BVH node visited, 32 B per leaf fetch of two spheres, "
-                        "16 B per aux row, ray records, queue entries read and written by the logic / sampling / shading kernels) "
+                        "16 B per aux row, ray records, queue entries read and written by the logic / shading kernels) "
                         "/ duration of the step's kernels from HIP events on the launch stream, against the aggregate L2 rate of "
                         "MI355X_MICROARCH.md (34.5 TB/s); the node and sphere fetches are per-lane 16-byte gathers, most of which "
                         "hit the vector L1",

@@ -612,7 +612,7 @@ uint32_t wfb_streams_log2(uint32_t n_pixels, uint32_t sample_count, uint32_t n_l
 // TWO PIPELINES. With a second stream from the caller (`st2`) and at least two sample streams per pixel, the streams are
 // dealt to two groups, each with its own queues and counters, and the groups' rounds run concurrently: group 0 on `st`,
 // group 1 on `st2` (forked from and joined to `st` with the two events). The traversal kernels wait on node fetches
-// for most of their cycles and leave HBM idle; the logic / sampling / shading kernels stream the queues through HBM and
+// for most of their cycles and leave HBM idle; the logic / shading kernels stream the queues through HBM and
 // leave the vector L1s idle; and every traversal launch ends with a tail in which a few long rays keep a few waves
 // busy. Two independent pipelines let the hardware fill each of these gaps with the other group's kernels.
 #ifndef WFB_GROUPS
