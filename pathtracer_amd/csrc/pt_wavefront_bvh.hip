@@ -113,8 +113,15 @@ __device__ __forceinline__ void light_sample(float4 l0, float4 l1, float4 l2, F3
 // The streams of a launch are dealt to 2^group_bits groups (the host's concurrent pipelines); group g owns the streams
 // whose top group_bits bits are g, and entry j of its queue is (pixel, stream) = (j >> (k - group_bits), g's j-th stream).
 __global__ __launch_bounds__(256) void wfb_init(Params P, const float4 *__restrict__ blob, WfQueue Q, uint32_t n, uint32_t group_bits,
-                                                uint32_t group) {
+                                                uint32_t group, uint32_t *__restrict__ jump) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0) {  // LCG jump-ahead constants of the light samples (wfb_traverse<ANY>): after j draws the state is A_j s + C_j inc
+        uint32_t A = 1u, C = 0u;
+        for (uint32_t k = 0; k < 4u * P.n_light; ++k) {
+            jump[2 * k] = A, jump[2 * k + 1] = C;
+            for (int d = 0; d < 2; ++d) C = C * 2891336453u + 1u, A *= 2891336453u;
+        }
+    }
     if (i >= n) return;
     TblGlobal tbl{blob};
     const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
@@ -692,21 +699,10 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
         }
         return err;
     };
-    // LCG jump-ahead constants of the light samples (wfb_traverse<ANY>): after j draws the state is A_j s + C_j inc
-    uint32_t jump[2 * 4 * 96];
-    const uint32_t n4 = 4u * P.n_light;
-    if (n4 > 4u * 96u) return join(hipErrorInvalidValue);  // (the API keeps scenes with more lights off this pipeline)
-    {
-        uint32_t A = 1u, C = 0u;
-        for (uint32_t k = 0; k < n4; ++k) {
-            jump[2 * k] = A, jump[2 * k + 1] = C;
-            for (int d = 0; d < 2; ++d) C = C * 2891336453u + 1u, A *= 2891336453u;
-        }
-    }
+    if (P.n_light > 96u) return join(hipErrorInvalidValue);  // the jump table lives in the counters block (the API keeps such scenes off this pipeline)
     for (uint32_t g = 0; g < n_groups; ++g) {
         if ((e = hipMemsetAsync(G[g].counters, 0, 4096, G[g].st)) != hipSuccess) return join(e);
-        if (n4 && (e = hipMemcpyAsync(G[g].counters + 256, jump, (size_t)n4 * 8, hipMemcpyHostToDevice, G[g].st)) != hipSuccess) return join(e);
-        hipLaunchKernelGGL(wfb_init, dim3(blocks_all), dim3(256), 0, G[g].st, P, blob, G[g].Q[0], n, group_bits, g);
+        hipLaunchKernelGGL(wfb_init, dim3(blocks_all), dim3(256), 0, G[g].st, P, blob, G[g].Q[0], n, group_bits, g, G[g].counters + 256);
     }
     const uint32_t max_iter = ((P.sample_count >> P.wf_streams_log2) + 1u) * P.max_depth + 1;
     uint32_t it = 0;
