@@ -27,7 +27,7 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
                                 void *workspace, hipStream_t st, uint32_t *iterations_out, unsigned long long *stats = nullptr,
                                 float *partial = nullptr, hipStream_t st2 = nullptr, hipEvent_t ev_fork = nullptr,
                                 hipEvent_t ev_join = nullptr);
-// sample streams per pixel (log2) for a launch of sample_count samples over n_pixels pixels: up to 2^27 paths in flight, queues of at most 64 GiB
+// sample streams per pixel (log2) for a launch of sample_count samples over n_pixels pixels: up to 2^28 paths in flight, queues of at most 96 GiB
 uint32_t wfb_streams_log2(uint32_t n_pixels, uint32_t sample_count, uint32_t n_light);
 // accum[i] += slice 0 + slice 1 + ... (fixed order) of `partial` (slices x n floats)
 hipError_t launch_add_slices(float *accum, const float *partial, uint32_t slices, size_t n, hipStream_t st);

@@ -20,7 +20,7 @@
 //                         sampling (renderer.rs:323-349) or phase-function scatter (:269-286)
 //
 // SAMPLE STREAMS. A queue entry is a (pixel, stream) pair: the samples of a launch are cut into 2^k contiguous parts
-// per pixel (P.wf_streams_log2, chosen by the host so that up to 2^27 paths are in flight) and every part is a stream with
+// per pixel (P.wf_streams_log2, chosen by the host so that up to 2^28 paths are in flight) and every part is a stream with
 // its own entry and its own slice of a partial-sum buffer that holds its running sum; the slices are added up in a
 // fixed order at the end.
 // Why: a round is five dependent launches, and each traversal launch lasts at least as long as its LONGEST ray — a
@@ -145,10 +145,13 @@ __global__ __launch_bounds__(256) void wfb_init(Params P, const float4 *__restri
 // STATS: also counts what the rays fetch (stats[0..3] = rays, nodes visited (32 B each), leaf fetches (two spheres,
 // 32 B, each), aux rows (16 B)), wave-reduced, for the memory roofline of bench.py --config c4.
 #ifndef WFB_INFLIGHT_LOG2
-#define WFB_INFLIGHT_LOG2 27  // paths in flight the host aims for (sample streams per pixel); C4: 2^24 -5 %, 2^25 0, 2^26 +3.2 %, 2^27 +5.3 %
+#define WFB_INFLIGHT_LOG2 28  // paths in flight the host aims for (sample streams per pixel); C4: 2^24 -5 %, 2^25 0, 2^26 +3.2 %, 2^27 +5.3 %, 2^28 +7 %
+#endif
+#ifndef WFB_MAX_STREAMS_LOG2
+#define WFB_MAX_STREAMS_LOG2 7u  // at most 128 sample streams per pixel
 #endif
 #ifndef WFB_QUEUE_CAP_GIB
-#define WFB_QUEUE_CAP_GIB 64  // queues of at most this many GiB of the GPU's 288 (C4 at 1080p: 53 GiB for 2^27 entries)
+#define WFB_QUEUE_CAP_GIB 96  // queues of at most this many GiB of the GPU's 288 (C4 at 1080p: 75 GiB for 2^28 entries; hippt_api.hip falls back to fewer streams when the allocation fails)
 #endif
 #ifndef WFB_TRAV_THREADS
 #define WFB_TRAV_THREADS 256
@@ -607,7 +610,7 @@ size_t wfb_workspace_bytes(uint32_t n_pixels, uint32_t n_light) {
 
 uint32_t wfb_streams_log2(uint32_t n_pixels, uint32_t sample_count, uint32_t n_light) {
     uint32_t lg = 0;
-    while (lg < 6u && ((uint64_t)n_pixels << (lg + 1)) <= (1ull << WFB_INFLIGHT_LOG2) && (2u << lg) <= sample_count &&
+    while (lg < WFB_MAX_STREAMS_LOG2 && ((uint64_t)n_pixels << (lg + 1)) <= (1ull << WFB_INFLIGHT_LOG2) && (2u << lg) <= sample_count &&
            wfb_layout(n_pixels << (lg + 1), n_light).total <= ((unsigned long long)WFB_QUEUE_CAP_GIB << 30) &&
            ((uint64_t)n_pixels << (lg + 1)) * 4u * std::max(1u, n_light) < (1ull << 32))  // shadow-ray ids k * cap + e are 32-bit
         ++lg;
