@@ -67,3 +67,16 @@ def test_lbvh_paths_equal_brute_force(name):
         assert np.quantile(e, 0.98) < 1e-5, (name, np.quantile(e, [0.5, 0.98, 1.0]))
         tot = b.sum(dtype=np.float64)
         assert abs(got.sum(dtype=np.float64) - tot) <= 1e-3 * tot
+
+
+def test_more_lights_than_the_queue_pipeline_takes():
+    """100 lights: the jump-ahead table of the queue pipeline holds 96, so the library renders the scene with the
+    one-kernel LBVH variant by itself (and refuses an explicit HIPPT_FLAG_WAVEFRONT); image == brute force."""
+    from pathtracer_amd import _abi, hip_renderer
+    s = cloud(seed=11, n=500, centre=(0, 0, 0), extent=(6, 3, 6), r_lo=0.1, r_hi=0.5, lights=100, w=40, h=24, spp=2)
+    a = hip_renderer.render_accum(s, seed=3)
+    b = hip_renderer.render_accum(s, seed=3, flags=_abi.FLAG_NO_BVH)
+    e = np.abs(a.astype(np.float64) - b).max(axis=2) / np.maximum(np.abs(b).max(axis=2), 1e-3 * b.max())
+    assert b.mean() > 0 and np.quantile(e, 0.98) < 1e-5
+    with pytest.raises(_abi.HipptError, match="96 lights"):
+        hip_renderer.render_accum(s, seed=3, flags=_abi.FLAG_WAVEFRONT)
