@@ -221,7 +221,11 @@ int hippt_set_scene(hippt_context *ctx, const hippt_scene *scene);
  * width*height*3 floats, caller-zeroed). Asynchronous on `stream` (a
  * hipStream_t, NULL = the context's own stream) for the megakernel variants; the queue
  * pipelines (HIPPT_FLAG_WAVEFRONT, and LBVH scenes by default) poll their queue
- * counters and therefore synchronise the stream before returning. This is the hot path
+ * counters and therefore synchronise the stream before returning. The LBVH queue pipeline keeps its
+ * path queues in device memory that the context allocates on first use and holds until hippt_destroy:
+ * up to 96 GiB for large images and sample counts (2^28 paths in flight), less when the GPU cannot
+ * spare it (it then runs fewer concurrent sample streams: slower, same image); it launches on a second
+ * internal stream forked from / joined to `stream`. This is the hot path
  * (src/renderer.rs:163-182 + 237-353 for every pixel). */
 int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts,
                               float *d_accum, void *stream);
