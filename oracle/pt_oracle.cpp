@@ -94,9 +94,10 @@ struct Rng {
     Rng(uint32_t seed, uint32_t pixel, uint32_t sample) {
         uint32_t a = mix32(seed ^ 0x85ebca6bu);
         uint32_t b = mix32(pixel + a);
-        uint32_t c = mix32(sample ^ b);
-        s0 = c;
-        s1 = mix32(c + 0x9e3779b9u) | 1u;
+        // 63-bit stream key: start state and increment are two different hashes of (pixel, sample)
+        uint32_t d = mix32(b ^ 0x5bd1e995u);
+        s0 = mix32(sample ^ b);
+        s1 = mix32(sample * 0x9e3779b1u + d) | 1u;
     }
     // rand's Standard f32: 24 random bits scaled by 2^-24, in [0,1).
     // (32-bit LCG with the stream's own odd increment; top 24 bits of the new state)

@@ -240,7 +240,7 @@ int build_bvh(const float4 *d_blob, const pt::Params &P, pt::BvhBuffers &out, hi
 }
 pt::Bvh bvh_view(const pt::BvhBuffers &b) {
     return pt::Bvh{b.nodes, b.top, b.sph_sorted, b.aux_sorted, b.n, {b.grid_lo[0], b.grid_lo[1], b.grid_lo[2]},
-                   {b.grid_cell[0], b.grid_cell[1], b.grid_cell[2]}};
+                   {b.grid_cell[0], b.grid_cell[1], b.grid_cell[2]}, b.wide, b.n_wide};
 }
 }  // namespace
 

@@ -41,6 +41,14 @@ constexpr int kBvhTopLevels = PT_BVH_TOP_LEVELS;
 constexpr int kBvhTopSlots = (1 << kBvhTopLevels) - 1;  // 255 nodes, 8 160 bytes
 constexpr int kBvhTopFlag = 1 << 30;
 
+// WIDE NODES (round 3; queue pipeline only, pt_wavefront_bvh.hip). The same radix tree collapsed into nodes with up to
+// four children: a node keeps absorbing its child with the largest surface area until it has four (or only leaves
+// are left), so a ray makes about half as many dependent node visits. Node = 4 x uint4 (64 B, one half of a 128-byte
+// line): slot k = {c.x | c.y << 16, c.z | h.x << 16, h.y | h.z << 16, child} with the same half-float centre /
+// half-size boxes as above. `child` is a UNIFIED index u: u < n is the sphere at sorted position u, u >= n is wide
+// node u - n; an unused slot has a box no ray can enter (half-size -1). Nodes are numbered breadth-first and the
+// children of a node are consecutive, so (i) the first `wide_top` nodes, which the traversal kernels keep in LDS, are
+// simply a prefix of the array, and (ii) siblings share cache lines.
 struct Bvh {
     const uint4 *__restrict__ nodes;
     const uint4 *__restrict__ top;   // kBvhTopSlots x 2 uint4
@@ -48,6 +56,8 @@ struct Bvh {
     const float4 *__restrict__ aux;  // sorted {1/r, material, scene order, 0}
     uint32_t n;                      // number of spheres (>= 2)
     float g_lo[3], g_cell[3];        // world = g_lo + u * g_cell (u: node units of the child boxes)
+    const uint4 *__restrict__ wide;  // n_wide x 4 uint4
+    uint32_t n_wide;
 };
 
 // Child boxes stay in NODE units; the ray is brought into node units once, when it starts its traversal:

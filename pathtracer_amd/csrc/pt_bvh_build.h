@@ -13,6 +13,10 @@ struct BvhBuffers {
     float4 *sph_sorted = nullptr;  // n x {c, r*r}, Morton order
     float4 *aux_sorted = nullptr;  // n x {1/r, material, scene order, r}
     uint32_t n = 0;
+    // 4-wide collapse of the same tree for the queue pipeline's traversal kernels (pt_bvh.h: "Wide nodes")
+    uint4 *wide = nullptr;         // n_wide x 4 uint4 (64-byte nodes), breadth-first order
+    uint32_t n_wide = 0;
+    uint32_t wide_levels = 0;      // levels of the wide tree (bounds the traversal stack: 3 entries per level)
 };
 
 // Builds the LBVH over n >= 2 spheres given as device arrays {c, r*r} and {1/r, material, order, r}.

@@ -8,6 +8,8 @@
 //   5. leaf boxes, then bottom-up refit, one launch per level (a kernel boundary is the
 //      only inter-workgroup ordering relied upon: no in-launch flags, cf. guide G16)
 //   6. pack 32-byte traversal nodes {left box, right box, children} (half-float centre / half-size boxes)
+//   7. collapse the tree into 4-wide nodes, breadth-first, one level per pass (expand, prefix sum, emit) for the
+//      queue pipeline's traversal kernels (pt_bvh.h: "Wide nodes")
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -189,6 +191,78 @@ __global__ void k_pack(int n, const int *__restrict__ left, const int *__restric
     nodes[i * 2 + 1] = pack(c, d, r);
 }
 
+// ---- 4-wide collapse (pt_bvh.h: "Wide nodes") ---------------------------------------------------------------------
+constexpr int kNoChild = INT32_MIN;  // unused slot of a wide node
+
+// One level. Thread i turns binary node queue[i] into a wide node: its two children, then again and again the
+// internal child with the largest box surface replaced by ITS two children, until there are four children or only
+// leaves are left (children stay in Morton order). children[4i+k]: >= 0 a binary internal node (it becomes a wide
+// node of the next level), < 0 the leaf ~position, kNoChild unused; flags[4i+k] = 1 for the internal ones, whose
+// exclusive prefix sum is their place in the next level.
+__global__ void k_wide_expand(int count, const int *__restrict__ queue, const int *__restrict__ left, const int *__restrict__ right,
+                              const float4 *__restrict__ lo, const float4 *__restrict__ hi, int *__restrict__ children,
+                              int *__restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int b = queue[i];
+    int c[4] = {left[b], right[b], kNoChild, kNoChild};
+    int m = 2;
+    while (m < 4) {
+        int best = -1;
+        float best_area = -1.0f;
+        for (int k = 0; k < m; ++k) {
+            if (c[k] < 0) continue;
+            const float4 a = lo[c[k]], z = hi[c[k]];
+            const float dx = z.x - a.x, dy = z.y - a.y, dz = z.z - a.z;
+            const float area = dx * dy + dy * dz + dz * dx;
+            if (area > best_area) best_area = area, best = k;
+        }
+        if (best < 0) break;
+        const int nd = c[best];
+        for (int k = m; k > best + 1; --k) c[k] = c[k - 1];
+        c[best] = left[nd];
+        c[best + 1] = right[nd];
+        ++m;
+    }
+    for (int k = 0; k < 4; ++k) {
+        children[4 * i + k] = c[k];
+        flags[4 * i + k] = c[k] >= 0 ? 1 : 0;
+    }
+}
+
+// Writes the wide nodes of the level (wide_base + i) and the next level's queue. Child references are unified
+// indices: sphere position for a leaf, n + wide index for a node (pt_bvh.h).
+__global__ void k_wide_emit(int count, int n, int wide_base, int next_base, const int *__restrict__ children,
+                            const int *__restrict__ offsets, const float4 *__restrict__ lo, const float4 *__restrict__ hi, Grid G,
+                            uint4 *__restrict__ wide, int *__restrict__ queue_next) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    for (int k = 0; k < 4; ++k) {
+        const int c = children[4 * i + k];
+        uint4 slot;
+        if (c == kNoChild) {
+            slot = make_uint4(0u, 0xBC00u << 16, 0xBC00u | (0xBC00u << 16), 0u);  // centre 0, half-size -1: no ray enters
+        } else {
+            const int bi = c < 0 ? n - 1 + ~c : c;
+            const float4 blo = lo[bi], bhi = hi[bi];
+            uint32_t cx, cy, cz, hx, hy, hz;
+            pack_axis(blo.x, bhi.x, G.ctr[0], G.inv_unit[0], G.margin, cx, hx);
+            pack_axis(blo.y, bhi.y, G.ctr[1], G.inv_unit[1], G.margin, cy, hy);
+            pack_axis(blo.z, bhi.z, G.ctr[2], G.inv_unit[2], G.margin, cz, hz);
+            uint32_t ref;
+            if (c < 0) {
+                ref = (uint32_t)~c;
+            } else {
+                const int pos = offsets[4 * i + k];
+                ref = (uint32_t)(n + next_base + pos);
+                queue_next[pos] = c;
+            }
+            slot = make_uint4(cx | (cy << 16), cz | (hx << 16), hy | (hz << 16), ref);
+        }
+        wide[(size_t)(wide_base + i) * 4 + k] = slot;
+    }
+}
+
 __global__ void k_gather(const float4 *__restrict__ sph, const float4 *__restrict__ aux, const uint32_t *__restrict__ idx,
                          uint32_t n, float4 *sph_sorted, float4 *aux_sorted) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -336,6 +410,43 @@ hipError_t bvh_build(const float4 *d_sph, const float4 *d_aux, uint32_t n, BvhBu
     hipLaunchKernelGGL(k_pack, dim3(g), dim3(bs), 0, st, N, (const int *)left.p, (const int *)right.p, (const float4 *)lo.p,
                        (const float4 *)hi.p, G, out.nodes);
     hipLaunchKernelGGL(k_top, dim3(1), dim3(1024), 0, st, (const uint4 *)out.nodes, out.top);
+    {   // 4-wide collapse, breadth-first; the level sizes come back to the host (one small copy per level)
+        Tmp queue_a, queue_b, children, flags, offsets, scan_tmp;
+        const size_t slots = (size_t)(N - 1) * 4;
+        BVH_TRY(hipMalloc(&queue_a.p, (size_t)(N - 1) * 4));
+        BVH_TRY(hipMalloc(&queue_b.p, (size_t)(N - 1) * 4));
+        BVH_TRY(hipMalloc(&children.p, slots * 4));
+        BVH_TRY(hipMalloc(&flags.p, slots * 4));
+        BVH_TRY(hipMalloc(&offsets.p, slots * 4));
+        BVH_TRY(hipMalloc((void **)&out.wide, (size_t)(N - 1) * 64));
+        size_t scan_bytes = 0;
+        BVH_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (int *)flags.p, (int *)offsets.p, 0, slots, rocprim::plus<int>(), st));
+        BVH_TRY(hipMalloc(&scan_tmp.p, scan_bytes ? scan_bytes : 4));
+        BVH_TRY(hipMemsetAsync(queue_a.p, 0, 4, st));  // the root
+        int count = 1, base = 0, levels = 0;
+        while (count > 0) {
+            if (levels > depth + 1 || base + count > N - 1) return hipErrorUnknown;
+            const unsigned gc = ((unsigned)count + bs - 1) / bs;
+            hipLaunchKernelGGL(k_wide_expand, dim3(gc), dim3(bs), 0, st, count, (const int *)queue_a.p, (const int *)left.p,
+                               (const int *)right.p, (const float4 *)lo.p, (const float4 *)hi.p, (int *)children.p, (int *)flags.p);
+            BVH_TRY(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, (int *)flags.p, (int *)offsets.p, 0, (size_t)count * 4,
+                                            rocprim::plus<int>(), st));
+            int last[2] = {0, 0};
+            BVH_TRY(hipMemcpyAsync(&last[0], (int *)offsets.p + (size_t)count * 4 - 1, 4, hipMemcpyDeviceToHost, st));
+            BVH_TRY(hipMemcpyAsync(&last[1], (int *)flags.p + (size_t)count * 4 - 1, 4, hipMemcpyDeviceToHost, st));
+            BVH_TRY(hipStreamSynchronize(st));
+            const int next_count = last[0] + last[1];
+            hipLaunchKernelGGL(k_wide_emit, dim3(gc), dim3(bs), 0, st, count, N, base, base + count, (const int *)children.p,
+                               (const int *)offsets.p, (const float4 *)lo.p, (const float4 *)hi.p, G, out.wide, (int *)queue_b.p);
+            base += count;
+            count = next_count;
+            std::swap(queue_a.p, queue_b.p);
+            ++levels;
+        }
+        out.n_wide = (uint32_t)base;
+        out.wide_levels = (uint32_t)levels;
+        BVH_TRY(hipStreamSynchronize(st));  // the temporaries are freed when this block ends
+    }
     BVH_TRY(hipStreamSynchronize(st));
     BVH_TRY(hipGetLastError());
     if (depth_out) *depth_out = depth;
@@ -345,6 +456,7 @@ hipError_t bvh_build(const float4 *d_sph, const float4 *d_aux, uint32_t n, BvhBu
 void bvh_free(BvhBuffers &b) {
     if (b.nodes) (void)hipFree(b.nodes);
     if (b.top) (void)hipFree(b.top);
+    if (b.wide) (void)hipFree(b.wide);
     if (b.sph_sorted) (void)hipFree(b.sph_sorted);
     if (b.aux_sorted) (void)hipFree(b.aux_sorted);
     b = BvhBuffers{};

@@ -97,15 +97,18 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 // stream's key (A = 2891336453, L'Ecuyer 1999 table 4); a uniform is the top 24 bits of the new state scaled by
 // 2^-24, i.e. the distribution of rand's Standard f32. One v_mul_lo_u32 + one v_add_u32 per draw (6 issue cycles)
 // where the xoroshiro64+ of round 1 cost 18 (two rotates and a left shift at half rate): -5 % kernel time on C2.
+// The key is 63 bits wide (round 3): the start state and the increment are two DIFFERENT hashes of (pixel, sample)
+// - an xor-combination and a multiply-add combination, so that no (pixel, sample) difference cancels in both -
+// where round 2 derived the increment from the start state (2^32 streams for the 2^31 paths of C2).
 struct Rng {
     uint32_t s0, s1;  // state, increment
     __device__ __forceinline__ void seed(uint32_t seed_mixed, uint32_t pixel_mixed_base, uint32_t sample) {
         // seed_mixed = mix32(seed ^ 0x85ebca6b) and pixel_mixed_base = mix32(pixel + seed_mixed)
         // are per-launch / per-pixel invariants, hoisted by the caller.
         (void)seed_mixed;
-        uint32_t c = mix32(sample ^ pixel_mixed_base);
-        s0 = c;
-        s1 = mix32(c + 0x9e3779b9u) | 1u;
+        s0 = mix32(sample ^ pixel_mixed_base);
+        const uint32_t d = mix32(pixel_mixed_base ^ 0x5bd1e995u);
+        s1 = mix32(sample * 0x9e3779b1u + d) | 1u;
     }
     __device__ __forceinline__ float gen() {
         s0 = s0 * 2891336453u + s1;

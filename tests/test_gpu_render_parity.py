@@ -158,7 +158,9 @@ def test_empty_scene_and_ragged_size():
 def test_wavefront_variant_matches_megakernel(oracle):
     """The queue-based pipeline (HIPPT_FLAG_WAVEFRONT) runs the same device code with the same RNG streams."""
     from pathtracer_amd import Scene, hip_renderer, _abi
-    for name, spp in (("scene.example.json", 24), ("glass_fog.json", 12)):
+    # (96 / 64 samples: at the 24 / 12 of round 2 ONE roughness-0.01 highlight sample — radiance ~100, and D amplifies a
+    # last-bit difference in n.h 1e4 times — was 0.7-1.1 % of these small images' totals)
+    for name, spp in (("scene.example.json", 96), ("glass_fog.json", 64)):
         s = Scene.load(os.path.join(ROOT, "scenes", name), 80, 60, spp)
         a = hip_renderer.render_accum(s, seed=9)
         b = hip_renderer.render_accum(s, seed=9, flags=_abi.FLAG_WAVEFRONT)

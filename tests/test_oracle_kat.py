@@ -243,6 +243,80 @@ def test_rng_distribution(oracle):
     assert abs(np.corrcoef(g[:-1].ravel(), g[1:].ravel())[0, 1]) < 0.06
 
 
+def _mix32(x):
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    x *= np.uint32(0x7feb352d)
+    x ^= x >> np.uint32(15)
+    x *= np.uint32(0x846ca68b)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def _stream_keys(seed, pixel, sample):
+    """numpy mirror of Rng's seeding (oracle/pt_oracle.cpp, pt_device.h): (start state, increment) per stream."""
+    pixel, sample = np.asarray(pixel, np.uint32), np.asarray(sample, np.uint32)
+    a = _mix32(np.array([seed], np.uint32) ^ np.uint32(0x85ebca6b))
+    b = _mix32(pixel + a)
+    d = _mix32(b ^ np.uint32(0x5bd1e995))
+    return _mix32(sample ^ b), _mix32(sample * np.uint32(0x9e3779b1) + d) | np.uint32(1)
+
+
+def _stream_draws(s0, inc, n):
+    out = np.empty((n,) + s0.shape, np.float64)
+    s = s0.copy()
+    for k in range(n):
+        s = s * np.uint32(2891336453) + inc
+        out[k] = (s >> np.uint32(8)) * 2.0 ** -24
+    return out
+
+
+def test_rng_streams_are_keyed_on_64_bits(oracle):
+    """VERDICT r02 weak #5: the increment is its own hash of (pixel, sample), not a function of the start state."""
+    with np.errstate(over="ignore"):
+        # the numpy mirror IS the oracle's stream
+        rs = np.random.default_rng(5)
+        for seed, p, smp in zip(rs.integers(0, 1 << 32, 48), rs.integers(0, 1 << 25, 48), rs.integers(0, 1 << 17, 48)):
+            s0, inc = _stream_keys(int(seed), np.array([p]), np.array([smp]))
+            assert np.array_equal(_stream_draws(s0, inc, 8)[:, 0].astype(np.float32), oracle.unit.rng(int(seed), int(p), int(smp), 8))
+        # no two of 2^24 (pixel, sample) keys share a stream: 4096 neighbouring pixels x 4096 consecutive samples,
+        # and the same count for pixels of two image rows at 8K with the showcase job's last samples
+        for pix0, smp0 in ((0, 0), (7680 * 2000 + 100, 131072 - 4096)):
+            pix, smp = np.meshgrid(np.arange(4096, dtype=np.uint32) + np.uint32(pix0),
+                                   np.arange(4096, dtype=np.uint32) + np.uint32(smp0), indexing="ij")
+            s0, inc = _stream_keys(0, pix.ravel(), smp.ravel())
+            key = (s0.astype(np.uint64) << np.uint64(32)) | inc.astype(np.uint64)
+            assert len(np.unique(key)) == key.size
+            # the old scheme's weakness, stated as a number: the start states alone DO collide (birthday in 32 bits)
+            assert len(np.unique(s0)) < s0.size
+            # ... and streams that share a start state have unrelated increments
+            order = np.argsort(s0, kind="stable")
+            same = s0[order][1:] == s0[order][:-1]
+            assert same.sum() > 1000 and (inc[order][1:][same] != inc[order][:-1][same]).all()
+        # one pixel, consecutive samples: draw k of stream s against draw k of stream s + 1 (k < 16)
+        s0, inc = _stream_keys(0, np.full(1 << 16, 12345, np.uint32), np.arange(1 << 16, dtype=np.uint32))
+        x = _stream_draws(s0, inc, 16)
+        for k in range(16):
+            assert abs(np.corrcoef(x[k, :-1], x[k, 1:])[0, 1]) < 0.02, k
+            h2 = np.histogram2d(x[k, 0::2], x[k, 1::2], bins=16, range=[[0, 1], [0, 1]])[0]
+            e = x.shape[1] / 2 / 256
+            assert ((h2 - e) ** 2 / e).sum() < 400, k                  # 255 dof
+            hist = np.bincount((x[k] * 64).astype(int), minlength=64)
+            assert ((hist - x.shape[1] / 64) ** 2 / (x.shape[1] / 64)).sum() < 130, k
+        # draws k and k + 1 ACROSS streams (what a wave's lanes consume together)
+        assert abs(np.corrcoef(x[:-1].ravel(), x[1:].ravel())[0, 1]) < 0.01
+        # neighbouring pixels (x + 1 and the next row at 1920), same sample: first 16 draws
+        pix = np.arange(1 << 16, dtype=np.uint32)
+        for dp in (1, 1920):
+            xa = _stream_draws(*_stream_keys(0, pix, np.full(pix.shape, 7, np.uint32)), 16)
+            xb = _stream_draws(*_stream_keys(0, pix + np.uint32(dp), np.full(pix.shape, 7, np.uint32)), 16)
+            for k in range(16):
+                assert abs(np.corrcoef(xa[k], xb[k])[0, 1]) < 0.02, (dp, k)
+                h2 = np.histogram2d(xa[k], xb[k], bins=16, range=[[0, 1], [0, 1]])[0]
+                e = len(pix) / 256
+                assert ((h2 - e) ** 2 / e).sum() < 400, (dp, k)
+
+
 # ---- integrator closed form (SURVEY §8c last row) ---------------------------------------
 def _quirk_brdf_integral(hit, n, v, color, metallic, rough, light, m=400):
     """float64 quadrature of renderer.rs:37-77 over the light rectangle (Q5: half of each edge vector)."""
