@@ -253,8 +253,8 @@ int hippt_resolve_device(hippt_context *ctx, const float *d_accum, uint32_t spp,
 int hippt_read_counters(hippt_context *ctx, uint64_t *counters);
 
 /* LBVH queue pipeline launched with HIPPT_FLAG_TRAVERSAL_STATS: what its traversal kernels fetched since the last
- * call (then zeroed): stats10 = {rays, nodes visited (32 B each), leaf fetches (two spheres = 32 B each), aux rows
- * (16 B each)} of the closest-hit traversals, then the same four of the shadow-ray traversals, then how many of the
+ * call (then zeroed): stats10 = {rays, 4-wide nodes visited (64 B each), spheres fetched (16 B each), aux rows read on
+ * exact ties (16 B each)} of the closest-hit traversals, then the same four of the shadow-ray traversals, then how many of the
  * node visits of either kind were served from the LDS copy of the tree's first levels. No reference analogue
  * (the reference's closest hit is a loop over all objects, src/renderer.rs:356-362): measurement only. */
 int hippt_read_traversal_stats(hippt_context *ctx, uint64_t *stats10);

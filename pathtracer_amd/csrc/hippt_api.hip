@@ -375,6 +375,7 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
     bool lds = (size_t)P.blob_f4 * sizeof(float4) <= kMaxLdsBlob;
     if (o.flags & HIPPT_FLAG_TABLES_GLOBAL) lds = false;
     bool use_bvh = ctx->bvh.n > 0 && !(o.flags & HIPPT_FLAG_NO_BVH);
+    const uint64_t pixels = (uint64_t)P.width * P.height;
     if (ctx->bvh_error_code && !(o.flags & HIPPT_FLAG_NO_BVH))
         return hippt_set_error(ctx->bvh_error_code, "%s (render with HIPPT_FLAG_NO_BVH for the brute-force loops)", ctx->bvh_error.c_str());
     if ((o.flags & HIPPT_FLAG_BVH) && !use_bvh) {
@@ -385,17 +386,20 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
         }
         use_bvh = true;
     }
-    uint64_t pixels = (uint64_t)P.width * P.height;
     bool wavefront = (o.flags & HIPPT_FLAG_WAVEFRONT) != 0;
     if ((o.flags & HIPPT_FLAG_WAVEFRONT) && (o.flags & HIPPT_FLAG_MEGAKERNEL))
         return hippt_set_error(HIPPT_ERR_INVALID, "HIPPT_FLAG_WAVEFRONT and HIPPT_FLAG_MEGAKERNEL are exclusive");
     // LBVH scenes default to the queue pipeline with persistent traversal kernels (2.4x the BVH megakernel on the
     // 100 000-sphere scene); the counting variant exists only as a megakernel
-    if (use_bvh && !(o.flags & HIPPT_FLAG_MEGAKERNEL) && !count && P.n_mat <= 0xffffu && P.max_depth <= 31u && P.n_light <= 96u) wavefront = true;
+    // (also kept off the queues: trees too large or deep for its item keys and stack, and images whose 4 L shadow samples
+    // per pixel would overflow the 32-bit ray ids even with one sample stream per pixel)
+    const bool queue_ok = use_bvh && pt::wfb_supports(ctx->bvh) && pixels * 4u * std::max(1u, P.n_light) < (1ull << 32);
+    if (use_bvh && !(o.flags & HIPPT_FLAG_MEGAKERNEL) && !count && P.n_mat <= 0xffffu && P.max_depth <= 31u && P.n_light <= 96u && queue_ok) wavefront = true;
     if (wavefront) {
-        if ((!use_bvh && !lds) || count || P.n_mat > 0xffffu || P.max_depth > 31u || (use_bvh && P.n_light > 96u))
+        if ((!use_bvh && !lds) || count || P.n_mat > 0xffffu || P.max_depth > 31u || (use_bvh && (P.n_light > 96u || !queue_ok)))
             return hippt_set_error(HIPPT_ERR_INVALID, "the wavefront variants support LDS-sized scenes or LBVH scenes, no counters, "
-                                                      "<= 65535 materials, max_depth <= 31 and (LBVH scenes) <= 96 lights");
+                                                      "<= 65535 materials, max_depth <= 31 and (LBVH scenes) <= 96 lights, < 2^24 spheres + nodes, "
+                                                      "pixels x 4 x lights < 2^32");
         // LBVH pipeline: several sample streams per pixel (pt_wavefront_bvh.hip), sized for the largest chunk of this call
         const uint64_t per_chunk = std::max<uint64_t>(1, kPathsPerLaunch / pixels);
         if (use_bvh && !(o.flags & HIPPT_FLAG_NO_SLICES))
@@ -458,7 +462,7 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
         if (wavefront && use_bvh) {
             pt::Params Pc = P;  // a short last chunk may have fewer samples than streams
             Pc.wf_streams_log2 = std::min(P.wf_streams_log2, pt::wfb_streams_log2((uint32_t)pixels, c, P.n_light));
-            HIP_TRY(pt::wavefront_bvh_render(Pc, ctx->d_blob, bvh_view(ctx->bvh), stack_entries, d_accum, ctx->wf_ws, st, nullptr,
+            HIP_TRY(pt::wavefront_bvh_render(Pc, ctx->d_blob, bvh_view(ctx->bvh), pt::wfb_stack_entries(ctx->bvh), d_accum, ctx->wf_ws, st, nullptr,
                                              (o.flags & HIPPT_FLAG_TRAVERSAL_STATS) ? ctx->d_counters + HIPPT_N_COUNTERS : nullptr,
                                              ctx->slice_buf, ctx->stream2, ctx->ev_fork, ctx->ev_join));
         }
@@ -499,6 +503,8 @@ int hippt_render_accum_device_noalloc(hippt_context *ctx, const hippt_options *o
     const uint32_t allowed = HIPPT_FLAG_COUNTERS | HIPPT_FLAG_NO_BVH | HIPPT_FLAG_TABLES_GLOBAL | HIPPT_FLAG_NO_SLICES | HIPPT_FLAG_MEGAKERNEL;
     if (o.flags & ~allowed)
         return hippt_set_error(HIPPT_ERR_INVALID, "hippt_render_accum_device_noalloc runs the table-scene megakernel only (flags 0x%x not supported)", o.flags & ~allowed);
+    if (ctx->bvh_error_code && !(o.flags & HIPPT_FLAG_NO_BVH))  // as hippt_render_accum_device: a failed LBVH build is reported, not papered over
+        return hippt_set_error(ctx->bvh_error_code, "%s (render with HIPPT_FLAG_NO_BVH for the brute-force loops)", ctx->bvh_error.c_str());
     if (ctx->bvh.n > 0 && !(o.flags & HIPPT_FLAG_NO_BVH))
         return hippt_set_error(HIPPT_ERR_INVALID, "hippt_render_accum_device_noalloc: LBVH scenes need the queue workspace of hippt_render_accum_device");
     if (ctx->device < 0 || ctx->device >= kMaxDevices || !g_scratch_ptr[ctx->device])

@@ -110,6 +110,13 @@ __device__ __forceinline__ float box_entry(const BoxRay &b, F3 c, F3 h, float t_
     return tmin <= tmax ? tmin : __builtin_inff();
 }
 
+// One slot of a wide node: entry distance of the ray into the child box, +inf on a miss (an unused slot always misses).
+__device__ __forceinline__ float slot_entry(const BoxRay &b, uint4 q, float t_max) {
+    auto lo16 = [](uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v & 0xffffu)); };
+    auto hi16 = [](uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16)); };
+    return box_entry(b, F3{lo16(q.x), hi16(q.x), lo16(q.y)}, F3{hi16(q.y), lo16(q.z), hi16(q.z)}, t_max);
+}
+
 // Closest sphere hit. best_t/best_leaf/best_ord are updated in place (start: inf, -1, ~0u).
 // stack: this lane's LDS column, element k at stack[k * stride].
 __device__ __forceinline__ void bvh_closest(const Bvh &B, const RayK &r, float &best_t, int &best_leaf,

@@ -27,6 +27,9 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
                                 void *workspace, hipStream_t st, uint32_t *iterations_out, unsigned long long *stats = nullptr,
                                 float *partial = nullptr, hipStream_t st2 = nullptr, hipEvent_t ev_fork = nullptr,
                                 hipEvent_t ev_join = nullptr);
+// whether the queue pipeline takes this tree (index width, depth), and the stack entries its rays may need
+bool wfb_supports(const BvhBuffers &b);
+uint32_t wfb_stack_entries(const BvhBuffers &b);
 // sample streams per pixel (log2) for a launch of sample_count samples over n_pixels pixels: up to 2^28 paths in flight, queues of at most 96 GiB
 uint32_t wfb_streams_log2(uint32_t n_pixels, uint32_t sample_count, uint32_t n_light);
 // accum[i] += slice 0 + slice 1 + ... (fixed order) of `partial` (slices x n floats)

@@ -137,13 +137,30 @@ __global__ __launch_bounds__(256) void wfb_init(Params P, const float4 *__restri
     if (i == 0) *Q.count = n;
 }
 
-// Persistent LBVH traversal over a ray array. ANY = false: closest sphere of ray i = entry i of Q
-// (same result as pt_bvh.h: bvh_closest); out: hit_t[i], hit_leaf[i] (-1: none). ANY = true: shadow ray r is light
-// sample k = r % 4L of shade-queue entry e = r / 4L — vertex-major, so the samples of one vertex are neighbouring lanes
-// that walk the same nodes (+5.3 % on C4 over a sample-major order) — origin Q.F_X[e] + 1e-4 l, direction l and tmax
-// from light_sample(); out: occ[k * cap + e] (same result as bvh_any; 1 also for samples that need no ray).
-// STATS: also counts what the rays fetch (stats[0..3] = rays, nodes visited (32 B each), leaf fetches (two spheres,
-// 32 B, each), aux rows (16 B)), wave-reduced, for the memory roofline of bench.py --config c4.
+// Persistent traversal of the 4-wide tree (pt_bvh.h: "Wide nodes") over a ray array. ANY = false: closest sphere of
+// ray i = entry i of Q (same result as pt_bvh.h: bvh_closest); out: hit_leaf[i] = sorted position of the sphere, -1:
+// none (wfb_logic forms t again from the sphere, so the 4 bytes are all a ray writes). ANY = true: shadow ray r is
+// light sample k = r % 4L of shade-queue entry e = r / 4L — vertex-major, so the samples of one vertex are
+// neighbouring lanes that walk the same nodes (+5.3 % on C4 over a sample-major order) — origin Q.F_X[e] + 1e-4 l,
+// direction l and tmax from light_sample(); out: bit r of occ_bits (same result as bvh_any; 1 also for samples that
+// need no ray).
+//
+// A lane works on ITEMS: a key [entry distance, truncated | unified index] names a wide node or a sphere. A trip
+// fetches the item in hand — 64 bytes of node (LDS for the first n_top nodes of the breadth-first array) or 16
+// bytes of sphere, all loads of a trip issued before the first is used — and then either tests the sphere or tests
+// the node's four child boxes, sorts the children it enters by distance (7 integer min / max / med3 on the keys),
+// stacks all but the nearest and goes on with that one; when nothing is entered it pops, skipping (closest) every
+// stacked item that begins beyond the best hit so far. The truncated distance in a key always rounds DOWN, so
+// skipping is conservative, and boxes are entered inclusively (t <= best), so a sphere that ties is still tested
+// and the scene-order rule of renderer.rs:359-361 decides.
+//
+// RESULTS ARE PACKED (round 3). A wave reserves rays 256 at a time; for shadow rays it keeps, per reserved range, 256
+// result bits and a count of unfinished rays in LDS (kSlots ranges at a time) and writes the 32 bytes once, when the
+// range is complete — round 2 stored one byte per ray when the ray ended, scattered over 4 L planes, and the
+// traversal kernels wrote 5x their algorithmic output to HBM (partial lines evicted again and again).
+//
+// STATS: also counts what the rays fetch (stats[0..3] = rays, wide nodes visited (64 B each), sphere fetches (16 B
+// each), aux rows read on exact ties (16 B)), wave-reduced, for the memory roofline of bench.py --config c4.
 #ifndef WFB_INFLIGHT_LOG2
 #define WFB_INFLIGHT_LOG2 28  // paths in flight the host aims for (sample streams per pixel); C4: 2^24 -5 %, 2^25 0, 2^26 +3.2 %, 2^27 +5.3 %, 2^28 +7 %
 #endif
@@ -156,54 +173,97 @@ __global__ __launch_bounds__(256) void wfb_init(Params P, const float4 *__restri
 #ifndef WFB_TRAV_THREADS
 #define WFB_TRAV_THREADS 256
 #endif
-constexpr uint32_t kTravThreads = WFB_TRAV_THREADS;  // traversal blocks: one LDS copy of the tree's top per 8 waves
+#ifndef WFB_WIDE_TOP
+#define WFB_WIDE_TOP 85  // wide nodes in LDS: four full levels
+#endif
+constexpr uint32_t kTravThreads = WFB_TRAV_THREADS;  // traversal blocks: one LDS copy of the tree's top per 4 waves
+constexpr uint32_t kWideTop = WFB_WIDE_TOP;
+constexpr uint32_t kSlots = 4;        // shadow rays: 256-ray ranges a wave may have unfinished at a time
+constexpr uint32_t kSlotWords = 12;   // 8 words of result bits, rays left, first ray of the range, 2 unused
+constexpr uint32_t kSlotFree = 0xffffffffu;
+constexpr uint32_t kSlotBytes = (kTravThreads / 64u) * kSlots * kSlotWords * 4u;
+constexpr uint32_t kKeyNone = 0xffffffffu;
 template <bool ANY, bool STATS = false>
 __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q, const float4 *__restrict__ blob,
                                                     const uint32_t *__restrict__ jump,
                                                     uint32_t *__restrict__ head,
-                                                    float *__restrict__ hit_t, int *__restrict__ hit_leaf,
-                                                    uint8_t *__restrict__ occ_out, unsigned long long *__restrict__ stats,
-                                                    uint32_t lds_entries, uint32_t *__restrict__ spill, uint32_t light_off = 0,
-                                                    uint32_t n_light = 0) {
+                                                    int *__restrict__ hit_leaf,
+                                                    uint32_t *__restrict__ occ_bits, unsigned long long *__restrict__ stats,
+                                                    uint32_t lds_entries, uint32_t *__restrict__ spill, uint32_t idx_bits, uint32_t n_top,
+                                                    uint32_t light_off = 0, uint32_t n_light = 0) {
     uint32_t st_rays = 0, st_nodes = 0, st_leaves = 0, st_aux = 0, st_top = 0;
-    extern __shared__ uint4 s_top[];  // the tree's first levels (kBvhTopSlots x 2 uint4), then stack_entries x kTravThreads words
-    for (uint32_t i = threadIdx.x; i < 2u * kBvhTopSlots; i += kTravThreads) s_top[i] = bvh.top[i];
+    extern __shared__ uint4 s_top[];  // the first n_top wide nodes (4 uint4 each), the waves' range slots, then lds_entries x kTravThreads stack words
+    for (uint32_t i = threadIdx.x; i < 4u * n_top; i += kTravThreads) s_top[i] = bvh.wide[i];
+    uint32_t *const slots_all = reinterpret_cast<uint32_t *>(s_top + 4u * n_top);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *const wsa = slots_all + (threadIdx.x >> 6) * (kSlots * kSlotWords);  // this wave's slots
+    volatile uint32_t *const ws = wsa;
+    if (lane < kSlots) {
+        ws[lane * kSlotWords + 8] = 0u;
+        ws[lane * kSlotWords + 9] = kSlotFree;
+    }
     __syncthreads();
-    uint32_t *stack = reinterpret_cast<uint32_t *>(s_top + 2 * kBvhTopSlots) + threadIdx.x;
+    uint32_t *stack = slots_all + kSlotBytes / 4u + threadIdx.x;
     const uint32_t stride = kTravThreads;
     // Stack entries beyond the first lds_entries live in this thread's column of a global spill area. The host sizes the
-    // LDS part so that 8 blocks fit a CU beside the heap copy of the tree's first levels (12 entries with 8 levels; the
-    // 23 entries C4's tree could need would allow 3 blocks) — few rays defer more nodes than that, so the spill path
-    // costs little: +2 % from the extra blocks, +1.2 % from the two extra LDS levels.
+    // LDS part so that 8 blocks fit a CU beside the copy of the tree's first levels — few rays defer more items than
+    // that, so the spill path costs little.
     uint32_t *const spill_col = spill + (size_t)blockIdx.x * kTravThreads + threadIdx.x;
     const size_t spill_stride = (size_t)gridDim.x * kTravThreads;
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t idx_mask = (1u << idx_bits) - 1u;
     // ANY: the "rays" are the 4 L light samples of every shade-queue entry, vertex-major (sample k of entry e is ray
     // e * 4 L + k): a lane that takes one regenerates the sample from the entry's stream state (LCG jump-ahead by 2 k
     // draws, table `jump` = {a^(2k), 1 + a + ... + a^(2k-1)}), drops it if it faces away from the surface or the
-    // light (renderer.rs:49: no shadow ray needed, occlusion byte 1) and otherwise traces it. There is no sampling
+    // light (renderer.rs:49: no shadow ray needed, result bit 1) and otherwise traces it. There is no sampling
     // kernel, no sample buffer and no ray list.
     const uint32_t n4 = 4u * n_light;
     const uint32_t n4_shift = (n4 & (n4 - 1u)) == 0u ? (uint32_t)__builtin_ctz(n4 | 0x80000000u) : 0xffffffffu;
     const uint32_t n_rays = ANY ? *Q.count * n4 : *Q.count;
-    const size_t cap = Q.cap;
 
     uint32_t w_next = 0, w_end = 0;  // this wave's reserved range of ray indices (wave-uniform)
+    uint32_t w_base = 0, cur_slot = 0;  // ANY: first ray and LDS slot of that range
     bool exhausted = false;          // the global queue has no ray left (wave-uniform)
     bool has = false;
-    uint32_t out_idx = 0;
+    uint32_t out_idx = 0;  // closest: ray index; ANY: slot << 8 | position in the slot's range
     RayK r{};
     BoxRay br{};
     float best_t = __builtin_inff(), lim = 0.0f, t_max = 0.0f;
     int best = -1;
-    uint32_t best_ord = 0xffffffffu;
-    int node = 0, sp = 0;
+    uint32_t cur = 0;  // the item in hand
+    int sp = 0;
+
+    // ANY: a ray's result goes into its range's bits; the range's count of unfinished rays goes down by one
+    auto settle = [&](uint32_t oi, bool occluded) {
+        const uint32_t s = oi >> 8, bit = oi & 255u;
+        if (occluded) atomicOr(&wsa[s * kSlotWords + (bit >> 5)], 1u << (bit & 31u));
+        atomicSub(&wsa[s * kSlotWords + 8], 1u);
+    };
 
     for (;;) {
         const unsigned long long idle = __ballot(!has);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if (n_idle >= kFetchMin) {
-            if (w_next == w_end && !exhausted) {
+            unsigned long long free_slots = 1ull;
+            if (ANY) {  // complete ranges go out as 32 bytes of bits and give their slot back
+                uint32_t s_rem = 1u, s_first = kSlotFree;
+                if (lane < kSlots) {
+                    s_rem = ws[lane * kSlotWords + 8];
+                    s_first = ws[lane * kSlotWords + 9];
+                }
+                unsigned long long done = __ballot(s_first != kSlotFree && s_rem == 0u);
+                while (done) {
+                    const uint32_t s = (uint32_t)__builtin_ctzll(done);
+                    done &= done - 1ull;
+                    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)s_first, (int)s);
+                    if (lane < 8u) occ_bits[(first >> 5) + lane] = ws[s * kSlotWords + lane];
+                    if (lane == s) {
+                        ws[s * kSlotWords + 9] = kSlotFree;
+                        s_first = kSlotFree;
+                    }
+                }
+                free_slots = __ballot(lane < kSlots && s_first == kSlotFree);
+            }
+            if (w_next == w_end && !exhausted && free_slots != 0ull) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(head, kFetchChunk);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -212,6 +272,13 @@ __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q,
                 } else {
                     w_next = base;
                     w_end = min(base + kFetchChunk, n_rays);
+                    if (ANY) {
+                        cur_slot = (uint32_t)__builtin_ctzll(free_slots);
+                        w_base = base;
+                        if (lane < 8u) ws[cur_slot * kSlotWords + lane] = 0u;
+                        if (lane == 8u) ws[cur_slot * kSlotWords + 8] = w_end - w_next;
+                        if (lane == 9u) ws[cur_slot * kSlotWords + 9] = base;
+                    }
                 }
             }
             const uint32_t avail = w_end - w_next;
@@ -233,9 +300,9 @@ __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q,
                         F3 l;
                         float tmax, inv_d2;
                         light_sample(l0, l1, l2, x, e1, e2, l, tmax, inv_d2);
-                        out_idx = k * (uint32_t)cap + e;
+                        out_idx = (cur_slot << 8) | (ridx - w_base);
                         take = (dot(nn, l) > 0.0f) & (-dot(l, f3(l4)) > 0.0f);
-                        if (!take) occ_out[out_idx] = 1;
+                        if (!take) settle(out_idx, true);
                         r = make_ray(madd(x, l, 1e-4f), l);
                         lim = tmax * tmax;
                         t_max = fsqrt(lim) * 1.000001f;
@@ -243,12 +310,11 @@ __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q,
                         r = make_ray(Q.ld3(F_RO, ridx), Q.ld3(F_RD, ridx));
                         best_t = __builtin_inff();
                         best = -1;
-                        best_ord = 0xffffffffu;
                         out_idx = ridx;
                     }
                     if (take) {
                         br = make_box_ray(bvh, r.ro, r.rd);
-                        node = kBvhTopFlag;  // the root, in LDS
+                        cur = bvh.n;  // the root: wide node 0, entry distance 0
                         sp = 0;
                         has = true;
                         if (STATS) ++st_rays;
@@ -256,94 +322,95 @@ __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q,
                 }
                 w_next += min(n_idle, avail);
             } else if (n_idle == 64u) {
-                break;  // exhausted and every lane is done
+                // exhausted and every lane is done (then every range is complete and was written above). With rays left in
+                // the queue an all-idle wave always has a free slot; should the bookkeeping ever be wrong, leaving is
+                // a wrong image, which the tests see, where spinning would hang the GPU.
+                break;
             }
         }
         if (!has) continue;
 
-        // ---- one node (pt_bvh.h: bvh_closest / bvh_any loop body) ----
-        uint4 na, nb4;
-        if (node & kBvhTopFlag) {
-            const int slot = node & (kBvhTopFlag - 1);
-            na = s_top[slot * 2 + 0], nb4 = s_top[slot * 2 + 1];
+        // ---- one item: fetch ----
+        const uint32_t u = cur & idx_mask;
+        const bool is_leaf = u < bvh.n;
+        const uint32_t w = u - bvh.n;
+        uint4 q0, q1 = uint4{0, 0, 0, 0}, q2 = q1, q3 = q1;
+        if (!is_leaf && w < n_top) {
+            q0 = s_top[w * 4u + 0u], q1 = s_top[w * 4u + 1u], q2 = s_top[w * 4u + 2u], q3 = s_top[w * 4u + 3u];
             if (STATS) ++st_top;
         } else {
-            na = bvh.nodes[node * 2 + 0], nb4 = bvh.nodes[node * 2 + 1];
+            const uint4 *p = is_leaf ? reinterpret_cast<const uint4 *>(bvh.sph) + u : bvh.wide + (size_t)w * 4u;
+            q0 = p[0];
+            if (!is_leaf) q1 = p[1], q2 = p[2], q3 = p[3];
         }
-        NodeBoxes nb = decode_node(na, nb4);
-        if (STATS) ++st_nodes;
-        int left = nb.left, right = nb.right;
-        const float bound = ANY ? t_max : best_t;
-        float tl = box_entry(br, nb.lc, nb.lh, bound);
-        float tr = box_entry(br, nb.rc, nb.rh, bound);
-        bool hl = tl < __builtin_inff(), hr = tr < __builtin_inff();
-        bool finished = false;
-        if (ANY) {
-            bool occ = false;
-            const bool ll = hl && left < 0, rl = hr && right < 0;
-            if (ll || rl) {  // both leaf spheres are fetched at once (one memory latency, not two); a lone leaf twice
-                const int il = ll ? ~left : ~right, ir = rl ? ~right : ~left;
-                const float4 sl = bvh.sph[il], sr = bvh.sph[ir];
-                if (STATS) ++st_leaves;
-                const float t0 = sphere_t(r, sl), t1 = sphere_t(r, sr);
-                occ = ((t0 > 0.0f) & (t0 * t0 < lim)) | ((t1 > 0.0f) & (t1 * t1 < lim));
-                if (ll) hl = false;
-                if (rl) hr = false;
-            }
-            if (occ) {
-                occ_out[out_idx] = 1;
-                finished = true;
-            }
-        } else {
-            auto leaf = [&](int lf, float4 sph) {
-                float t = sphere_t(r, sph);
-                if (t > 0.0f && t <= best_t) {
-                    uint32_t ord = __float_as_uint(bvh.aux[lf].z);
-                    if (STATS) ++st_aux;
-                    if (t < best_t || ord < best_ord) {  // renderer.rs:359-361: first minimum in scene order
-                        best_t = t;
-                        best = lf;
-                        best_ord = ord;
-                    }
-                }
-            };
-            const bool ll = hl && left < 0, rl = hr && right < 0;
-            if (ll || rl) {  // both leaf spheres are fetched at once (one memory latency, not two)
-                const int il = ll ? ~left : ~right, ir = rl ? ~right : ~left;
-                const float4 sl = bvh.sph[il], sr = bvh.sph[ir];
-                if (STATS) ++st_leaves;
-                leaf(il, sl);
-                if (ll && rl) leaf(ir, sr);
-                if (ll) hl = false;
-                if (rl) hr = false;
-            }
-        }
-        if (!finished) {
-            if (hl && hr) {
-                bool lfirst = (ANY && !WFB_ANY_NEAR_FIRST) ? true : (tl <= tr);
-                const uint32_t other = (uint32_t)(lfirst ? right : left);
-                if ((uint32_t)sp < lds_entries) stack[sp * stride] = other;
-                else spill_col[((uint32_t)sp - lds_entries) * spill_stride] = other;
-                ++sp;
-                node = lfirst ? left : right;
-            } else if (hl || hr) {
-                node = hl ? left : right;
-            } else if (sp == 0) {
-                finished = true;
-                if (ANY) {
-                    occ_out[out_idx] = 0;
+        bool finished = false, need_pop = false;
+        if (is_leaf) {
+            // ---- a sphere ----
+            if (STATS) ++st_leaves;
+            const float t = sphere_t(r, float4{__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z), __uint_as_float(q0.w)});
+            if (ANY) {
+                if ((t > 0.0f) & (t * t < lim)) {
+                    settle(out_idx, true);
+                    finished = true;
                 } else {
-                    hit_t[out_idx] = best_t;
-                    hit_leaf[out_idx] = best;
+                    need_pop = true;
                 }
             } else {
+                if (t > 0.0f && t <= best_t) {
+                    if (t < best_t) {
+                        best_t = t;
+                        best = (int)u;
+                    } else if (best >= 0) {  // exact tie: renderer.rs:359-361, first minimum in scene order
+                        const uint32_t ord_new = __float_as_uint(bvh.aux[u].z), ord_old = __float_as_uint(bvh.aux[best].z);
+                        if (STATS) st_aux += 2u;
+                        if (ord_new < ord_old) best = (int)u;
+                    }
+                }
+                need_pop = true;
+            }
+        } else {
+            // ---- a wide node: enter the child boxes, nearest first ----
+            if (STATS) ++st_nodes;
+            const float bound = ANY ? t_max : best_t;  // inclusive: a sphere that ties must still be visited
+            auto key = [&](uint4 q) {
+                const float t = slot_entry(br, q, bound);
+                return t < __builtin_inff() ? (((__float_as_uint(t) << 1) & ~idx_mask) | q.w) : kKeyNone;
+            };
+            const uint32_t k0 = key(q0), k1 = key(q1), k2 = key(q2), k3 = key(q3);
+            // sorted ascending (misses, kKeyNone, last): min3 / med3 / max3 of three, then the fourth put in place
+            const uint32_t lo3 = min(min(k0, k1), k2), hi3 = max(max(k0, k1), k2);
+            const uint32_t md3 = max(min(k0, k1), min(max(k0, k1), k2));
+            const uint32_t a0 = min(lo3, k3), a3 = max(hi3, k3);
+            const uint32_t a1 = max(min(lo3, md3), min(max(lo3, md3), k3));  // med3(lo3, md3, k3)
+            const uint32_t a2 = max(min(md3, hi3), min(max(md3, hi3), k3));  // med3(md3, hi3, k3)
+            auto push = [&](uint32_t item) {
+                if ((uint32_t)sp < lds_entries) stack[sp * stride] = item;
+                else spill_col[((uint32_t)sp - lds_entries) * spill_stride] = item;
+                ++sp;
+            };
+            if (a3 != kKeyNone) push(a3);
+            if (a2 != kKeyNone) push(a2);
+            if (a1 != kKeyNone) push(a1);
+            if (a0 != kKeyNone) cur = a0;
+            else need_pop = true;
+        }
+        if (need_pop) {
+            const uint32_t best_key = __float_as_uint(best_t) << 1;
+            for (;;) {
+                if (sp == 0) {
+                    finished = true;
+                    if (ANY) settle(out_idx, false);
+                    else hit_leaf[out_idx] = best;
+                    break;
+                }
                 --sp;
                 if (__builtin_expect((uint32_t)sp < lds_entries, 1)) {
-                    node = (int)stack[sp * stride];
+                    cur = stack[sp * stride];
                 } else {  // (the barrier keeps the two loads apart: merged, they become one flat load with a selected address)
-                    node = (int)spill_col[((uint32_t)sp - lds_entries) * spill_stride];
-                    asm volatile("" : "+v"(node));
+                    cur = spill_col[((uint32_t)sp - lds_entries) * spill_stride];
+                    asm volatile("" : "+v"(cur));
                 }
+                if (ANY || (cur & ~idx_mask) <= best_key) break;  // an item that begins beyond the best hit cannot improve it
             }
         }
         if (finished) has = false;
@@ -360,7 +427,7 @@ __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q,
 
 // Everything of one path vertex that follows the closest-sphere query and precedes next-event estimation.
 __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restrict__ blob, Bvh bvh, WfQueue Qin,
-                                                 const float *__restrict__ hit_t, const int *__restrict__ hit_leaf,
+                                                 const int *__restrict__ hit_leaf,
                                                  WfQueue Qnext, WfQueue Qshade, float *__restrict__ accum) {
     __shared__ uint32_t s_cnt[2][4], s_base[2];
     TblGlobal tbl{blob};
@@ -391,8 +458,9 @@ __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restr
 
             // pt_trace.h: Tracer::closest after bvh_closest — planes, then the winner with the reference's roundings
             RayK ray = make_ray(ro, rd);
-            float best_t = hit_t[qi];
+            // the traversal hands over the sphere only; its t is formed again here, by the same sphere_t() on the same ray
             int best = hit_leaf[qi];
+            float best_t = best >= 0 ? sphere_t(ray, bvh.sph[best]) : __builtin_inff();
             closest_planes(tbl, P, ray, best_t, best, [&](int id) { return __float_as_uint(bvh.aux[id].z); });
             HitRec h{best_t, best};
             refine_hit(tbl, P, ray.ro, ray.rd, h, [&](int id) { return bvh.sph[id]; });
@@ -463,12 +531,11 @@ __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restr
 }
 
 __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restrict__ blob, WfQueue Qshade,
-                                                 const uint8_t *__restrict__ occ_sph,
+                                                 const uint32_t *__restrict__ occ_bits,
                                                  WfQueue Qnext, float *__restrict__ accum) {
     __shared__ uint32_t s_cnt[2][4], s_base[2];
     TblGlobal tbl{blob};
     const uint32_t count = *Qshade.count;
-    const size_t cap = Qshade.cap;
     const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
     for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
         uint32_t qi = base + threadIdx.x;
@@ -509,7 +576,8 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
                     float e1 = rng.gen() - 0.5f;
                     float e2 = rng.gen() - 0.5f;
                     light_sample(l0, l1, l2, x, e1, e2, l[s], tmax[s], id2[s]);
-                    occ[s] = occ_sph[(size_t)(li * 4 + s) * cap + qi] != 0;
+                    const uint32_t rbit = qi * (4u * P.n_light) + li * 4u + (uint32_t)s;  // wfb_traverse<ANY>: ray e * 4 L + k
+                    occ[s] = ((occ_bits[rbit >> 5] >> (rbit & 31u)) & 1u) != 0u;
                 }
                 uint32_t c0 = 0, c1 = 0;
                 occluded_multi<TblGlobal, 4, false>(tbl, P, x, 1e-4f, l, tmax, occ, c0, c1, false);
@@ -586,7 +654,10 @@ struct WfbLayout {
     size_t per_queue, hits, occ, total;
 };
 constexpr unsigned kGridTrav = 256u * 8u * 256u / kTravThreads;  // persistent traversal blocks: every CU full
-constexpr uint32_t kLdsEntriesMax = (160u * 1024u / 8u - kBvhTopSlots * 32u) / (kTravThreads * 4u);  // 8 blocks per CU: 12 entries beside an 8-level heap
+// stack entries in LDS with 8 blocks per CU: what is left of 20 KB beside the first kWideTop wide nodes and the range slots (13 for 85 nodes)
+constexpr uint32_t kLdsEntriesMax = (160u * 1024u / 8u - kWideTop * 64u - kSlotBytes) / (kTravThreads * 4u);
+// a ray stacks at most three items per level of the wide tree; deeper trees than this stay with the one-kernel LBVH variant
+constexpr uint32_t kWideStackCap = 3u * 48u + 1u;
 // stack entries that do not fit the LDS part, one column per traversal thread, shared by all traversal launches of a stream
 size_t wfb_spill_bytes(uint32_t stack_entries) {
     return stack_entries > kLdsEntriesMax ? (size_t)(stack_entries - kLdsEntriesMax) * kGridTrav * kTravThreads * 4 : 256;
@@ -595,17 +666,24 @@ WfbLayout wfb_layout(uint32_t n, uint32_t n_light) {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     WfbLayout L;
     L.per_queue = al((size_t)n * 4 * (NF + NU));
-    L.hits = al((size_t)n * 8);
-    L.occ = al((size_t)n * 4 * std::max(1u, n_light));
+    L.hits = al((size_t)n * 4);                                          // closest rays: the sphere, 4 bytes
+    L.occ = al((size_t)n * 4 * std::max(1u, n_light) / 8 + 64);          // shadow rays: one bit each, written 32 bytes at a time
     L.total = 4096 + 3 * L.per_queue + L.hits + L.occ;
     return L;
 }
 }  // namespace
 
+// The queue pipeline takes trees whose unified index (spheres + wide nodes) leaves at least 8 bits of a key for the
+// entry distance and whose depth fits the stack cap; hippt_api.hip keeps other scenes on the one-kernel LBVH variant.
+bool wfb_supports(const BvhBuffers &b) {
+    return b.wide && b.n_wide > 0 && (uint64_t)b.n + b.n_wide <= (1ull << 24) && 3u * b.wide_levels + 1u <= kWideStackCap;
+}
+uint32_t wfb_stack_entries(const BvhBuffers &b) { return std::max(8u, 3u * b.wide_levels + 1u); }
+
 // room for one pipeline over n entries or two over n / 2 each
 size_t wfb_workspace_bytes(uint32_t n_pixels, uint32_t n_light) {
     return std::max(wfb_layout(n_pixels, n_light).total, 2 * wfb_layout((n_pixels + 1) / 2, n_light).total) +
-           2 * ((wfb_spill_bytes((uint32_t)BVH_STACK) + 255) & ~(size_t)255);
+           2 * ((wfb_spill_bytes(kWideStackCap) + 255) & ~(size_t)255);
 }
 
 uint32_t wfb_streams_log2(uint32_t n_pixels, uint32_t sample_count, uint32_t n_light) {
@@ -642,18 +720,17 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
         hipStream_t st;
         uint32_t *counters;  // [0],[1]: ray queue counts (ping-pong), [2]: shade count, [3],[4]: fetch heads; [256..]: the jump table
         WfQueue Q[3];
-        float *hit_t;
         int *hit_leaf;
-        uint8_t *occ;
+        uint32_t *occ;
         uint32_t *spill;
         bool done;
     } G[2];
     uint32_t lds_entries = std::min(stack_entries, kLdsEntriesMax);
     if (const char *dbg = getenv("HIPPT_WFB_LDS_STACK")) {  // test hook: a small LDS part forces the spill path (tests/test_gpu_bvh.py)
         const long v = strtol(dbg, nullptr, 10);
-        if (v >= 1 && (uint32_t)v < lds_entries && stack_entries - (uint32_t)v <= (uint32_t)BVH_STACK - kLdsEntriesMax) lds_entries = (uint32_t)v;
+        if (v >= 1 && (uint32_t)v < lds_entries && stack_entries - (uint32_t)v <= kWideStackCap - kLdsEntriesMax) lds_entries = (uint32_t)v;
     }
-    const size_t spill_bytes = (wfb_spill_bytes((uint32_t)BVH_STACK) + 255) & ~(size_t)255;
+    const size_t spill_bytes = (wfb_spill_bytes(kWideStackCap) + 255) & ~(size_t)255;
     for (uint32_t g = 0; g < n_groups; ++g) {
         uint8_t *w = (uint8_t *)workspace + (size_t)g * (L.total + spill_bytes);
         G[g].spill = (uint32_t *)(w + L.total);
@@ -667,17 +744,20 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
             G[g].Q[k].cap = n;
         }
         w += 3 * L.per_queue;
-        G[g].hit_t = (float *)w;
-        G[g].hit_leaf = (int *)(w + (size_t)n * 4);
+        G[g].hit_leaf = (int *)w;
         w += L.hits;
-        G[g].occ = w;
+        G[g].occ = (uint32_t *)w;
         G[g].done = false;
     }
 
     const unsigned blocks_all = (n + 255) / 256;
     const unsigned grid = std::min(blocks_all, 256u * 8u);
     const unsigned grid_trav = kGridTrav;
-    const size_t stack_bytes = (size_t)kBvhTopSlots * 32 + (size_t)lds_entries * kTravThreads * 4;
+    if (stack_entries > kWideStackCap || !bvh.wide || (uint64_t)bvh.n + bvh.n_wide > (1ull << 24)) return hipErrorInvalidValue;  // wfb_supports()
+    const uint32_t n_top = std::min(bvh.n_wide, kWideTop);
+    uint32_t idx_bits = 1;
+    while ((1ull << idx_bits) < (uint64_t)bvh.n + bvh.n_wide) ++idx_bits;
+    const size_t stack_bytes = (size_t)n_top * 64 + kSlotBytes + (size_t)lds_entries * kTravThreads * 4;
     hipError_t e;
     if (P.sample_count == 0) return hipSuccess;
     if (stack_bytes > 64 * 1024) {  // more dynamic LDS than a launch may ask for by default
@@ -720,22 +800,22 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
             if ((e = hipMemsetAsync(&counters[2], 0, 16, s)) != hipSuccess) return join(e);  // shade count, both fetch heads
             if (stats)
                 hipLaunchKernelGGL((WFB_TRAV<false, true>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[cur], (const float4 *)nullptr,
-                                   (const uint32_t *)nullptr, &counters[3], A.hit_t, A.hit_leaf, (uint8_t *)nullptr, stats, lds_entries, A.spill);
+                                   (const uint32_t *)nullptr, &counters[3], A.hit_leaf, (uint32_t *)nullptr, stats, lds_entries, A.spill, idx_bits, n_top);
             else
                 hipLaunchKernelGGL((WFB_TRAV<false, false>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[cur], (const float4 *)nullptr,
-                                   (const uint32_t *)nullptr, &counters[3], A.hit_t, A.hit_leaf, (uint8_t *)nullptr,
-                                   (unsigned long long *)nullptr, lds_entries, A.spill);
-            hipLaunchKernelGGL(wfb_logic, dim3(grid), dim3(256), 0, s, P, blob, bvh, A.Q[cur], (const float *)A.hit_t,
+                                   (const uint32_t *)nullptr, &counters[3], A.hit_leaf, (uint32_t *)nullptr,
+                                   (unsigned long long *)nullptr, lds_entries, A.spill, idx_bits, n_top);
+            hipLaunchKernelGGL(wfb_logic, dim3(grid), dim3(256), 0, s, P, blob, bvh, A.Q[cur],
                                (const int *)A.hit_leaf, A.Q[1 - cur], A.Q[2], sums);
             if (stats)
                 hipLaunchKernelGGL((WFB_TRAV<true, true>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[2], blob,
-                                   (const uint32_t *)(counters + 256), &counters[4], (float *)nullptr, (int *)nullptr, A.occ,
-                                   stats, lds_entries, A.spill, P.light_off, P.n_light);
+                                   (const uint32_t *)(counters + 256), &counters[4], (int *)nullptr, A.occ,
+                                   stats, lds_entries, A.spill, idx_bits, n_top, P.light_off, P.n_light);
             else
                 hipLaunchKernelGGL((WFB_TRAV<true, false>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[2], blob,
-                                   (const uint32_t *)(counters + 256), &counters[4], (float *)nullptr, (int *)nullptr, A.occ,
-                                   (unsigned long long *)nullptr, lds_entries, A.spill, P.light_off, P.n_light);
-            hipLaunchKernelGGL(wfb_shade, dim3(grid), dim3(256), 0, s, P, blob, A.Q[2], (const uint8_t *)A.occ,
+                                   (const uint32_t *)(counters + 256), &counters[4], (int *)nullptr, A.occ,
+                                   (unsigned long long *)nullptr, lds_entries, A.spill, idx_bits, n_top, P.light_off, P.n_light);
+            hipLaunchKernelGGL(wfb_shade, dim3(grid), dim3(256), 0, s, P, blob, A.Q[2], (const uint32_t *)A.occ,
                                A.Q[1 - cur], sums);
         }
         cur = 1 - cur;
