@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void wf_shade(Params P, const float4 *__restri
 // ---- host driver -----------------------------------------------------------------------
 size_t wf_workspace_bytes(uint32_t n_pixels) {
     // three queues x (NF float + NU uint planes) + counters
-    size_t per_queue = ((size_t)n_pixels * 4 * (NF + NU) + 511) & ~(size_t)255;
+    size_t per_queue = (queue_bytes(n_pixels) + 511) & ~(size_t)255;
     return 3 * per_queue + 4096;
 }
 
@@ -273,11 +273,10 @@ hipError_t wavefront_render(const Params &P, const float4 *blob, float *accum, v
     uint8_t *w = (uint8_t *)workspace;
     uint32_t *counters = (uint32_t *)w;  // [0],[1]: ray queue counts (ping-pong), [2]: shade queue count
     w += 4096;
-    size_t per_queue = ((size_t)n * 4 * (NF + NU) + 511) & ~(size_t)255;
+    size_t per_queue = (queue_bytes(n) + 511) & ~(size_t)255;
     WfQueue Q[3];
     for (int k = 0; k < 3; ++k) {
         Q[k].f = (float *)(w + per_queue * k);
-        Q[k].u = (uint32_t *)(w + per_queue * k + (size_t)n * 4 * NF);
         Q[k].count = &counters[k];
         Q[k].cap = n;
     }

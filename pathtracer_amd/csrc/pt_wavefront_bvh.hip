@@ -183,8 +183,11 @@ constexpr uint32_t kSlotWords = 12;   // 8 words of result bits, rays left, firs
 constexpr uint32_t kSlotFree = 0xffffffffu;
 constexpr uint32_t kSlotBytes = (kTravThreads / 64u) * kSlots * kSlotWords * 4u;
 constexpr uint32_t kKeyNone = 0xffffffffu;
+#ifndef WFB_TRAV_MIN_BLOCKS
+#define WFB_TRAV_MIN_BLOCKS 1
+#endif
 template <bool ANY, bool STATS = false>
-__global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q, const float4 *__restrict__ blob,
+__global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_traverse(Bvh bvh, WfQueue Q, const float4 *__restrict__ blob,
                                                     const uint32_t *__restrict__ jump,
                                                     uint32_t *__restrict__ head,
                                                     int *__restrict__ hit_leaf,
@@ -376,7 +379,12 @@ __global__ __launch_bounds__(kTravThreads) void wfb_traverse(Bvh bvh, WfQueue Q,
                 const float t = slot_entry(br, q, bound);
                 return t < __builtin_inff() ? (((__float_as_uint(t) << 1) & ~idx_mask) | q.w) : kKeyNone;
             };
-            const uint32_t k0 = key(q0), k1 = key(q1), k2 = key(q2), k3 = key(q3);
+            uint32_t k0 = key(q0), k1 = key(q1), k2 = key(q2), k3 = key(q3);
+            if (ANY && !WFB_ANY_NEAR_FIRST) {  // experiment: shadow rays in slot order (entered children first, unsorted)
+                const uint32_t m = ~idx_mask;
+                k0 = k0 == kKeyNone ? k0 : (k0 & idx_mask), k1 = k1 == kKeyNone ? k1 : ((k1 & idx_mask) | (m & 0x10000000u));
+                k2 = k2 == kKeyNone ? k2 : ((k2 & idx_mask) | (m & 0x20000000u)), k3 = k3 == kKeyNone ? k3 : ((k3 & idx_mask) | (m & 0x30000000u));
+            }
             // sorted ascending (misses, kKeyNone, last): min3 / med3 / max3 of three, then the fourth put in place
             const uint32_t lo3 = min(min(k0, k1), k2), hi3 = max(max(k0, k1), k2);
             const uint32_t md3 = max(min(k0, k1), min(max(k0, k1), k2));
@@ -665,7 +673,7 @@ size_t wfb_spill_bytes(uint32_t stack_entries) {
 WfbLayout wfb_layout(uint32_t n, uint32_t n_light) {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     WfbLayout L;
-    L.per_queue = al((size_t)n * 4 * (NF + NU));
+    L.per_queue = al(queue_bytes(n));
     L.hits = al((size_t)n * 4);                                          // closest rays: the sphere, 4 bytes
     L.occ = al((size_t)n * 4 * std::max(1u, n_light) / 8 + 64);          // shadow rays: one bit each, written 32 bytes at a time
     L.total = 4096 + 3 * L.per_queue + L.hits + L.occ;
@@ -739,7 +747,6 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
         w += 4096;
         for (int k = 0; k < 3; ++k) {
             G[g].Q[k].f = (float *)(w + L.per_queue * k);
-            G[g].Q[k].u = (uint32_t *)(w + L.per_queue * k + (size_t)n * 4 * NF);
             G[g].Q[k].count = &G[g].counters[k];
             G[g].Q[k].cap = n;
         }
