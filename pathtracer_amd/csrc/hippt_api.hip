@@ -393,7 +393,7 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
     // 100 000-sphere scene); the counting variant exists only as a megakernel
     // (also kept off the queues: trees too large or deep for its item keys and stack, and images whose 4 L shadow samples
     // per pixel would overflow the 32-bit ray ids even with one sample stream per pixel)
-    const bool queue_ok = use_bvh && pt::wfb_supports(ctx->bvh) && pixels * 4u * std::max(1u, P.n_light) < (1ull << 32);
+    const bool queue_ok = use_bvh && pt::wfb_supports(ctx->bvh) && pixels * 3u * 4u * std::max(1u, P.n_light) < pt::wfb_max_ray_ids();  // (a queue may hold up to 3 positions per entry)
     if (use_bvh && !(o.flags & HIPPT_FLAG_MEGAKERNEL) && !count && P.n_mat <= 0xffffu && P.max_depth <= 31u && P.n_light <= 96u && queue_ok) wavefront = true;
     if (wavefront) {
         if ((!use_bvh && !lds) || count || P.n_mat > 0xffffu || P.max_depth > 31u || (use_bvh && (P.n_light > 96u || !queue_ok)))

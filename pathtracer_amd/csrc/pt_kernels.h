@@ -30,6 +30,7 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
 // whether the queue pipeline takes this tree (index width, depth), and the stack entries its rays may need
 bool wfb_supports(const BvhBuffers &b);
 uint32_t wfb_stack_entries(const BvhBuffers &b);
+uint64_t wfb_max_ray_ids();  // pixels x streams x 4 x lights must stay below this
 // sample streams per pixel (log2) for a launch of sample_count samples over n_pixels pixels: up to 2^28 paths in flight, queues of at most 96 GiB
 uint32_t wfb_streams_log2(uint32_t n_pixels, uint32_t sample_count, uint32_t n_light);
 // accum[i] += slice 0 + slice 1 + ... (fixed order) of `partial` (slices x n floats)

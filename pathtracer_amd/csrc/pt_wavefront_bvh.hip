@@ -47,7 +47,15 @@ namespace {
 #ifndef WFB_ANY_NEAR_FIRST
 #define WFB_ANY_NEAR_FIRST 1  // +1.8 % on C4 with the vertex-major list (was -1 % with the sample-major one)
 #endif
-constexpr uint32_t kFetchChunk = 256;          // rays a wave reserves with one atomic
+#ifndef WFB_RESERVE
+#define WFB_RESERVE 2048
+#endif
+constexpr uint32_t kFetchChunk = 256;          // rays of one range of a wave (one slot of result bits)
+// Rays a wave reserves with ONE atomic on the launch's fetch head, consumed range by range. Same-address atomics
+// complete one every ~8 ns chip-wide, so with 256 rays per atomic no traversal launch could take more than ~33 G rays
+// per second however fast the traversal itself was, and the shadow-ray launches (4 L "rays" per vertex, a third of
+// them dropped at once) ran close to that.
+constexpr uint32_t kReserve = WFB_RESERVE;
 constexpr uint32_t kFetchMin = WFB_FETCH_MIN;  // idle lanes that trigger a refill (C4, final pipeline: 4: -12 %, 8: -4 %, 16: best, 24: -1 %)
 
 // Entry id v = pixel << k | stream. Stream j of 2^k renders the j-th part of the launch's samples (parts differ by at
@@ -223,7 +231,8 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
     const uint32_t n4_shift = (n4 & (n4 - 1u)) == 0u ? (uint32_t)__builtin_ctz(n4 | 0x80000000u) : 0xffffffffu;
     const uint32_t n_rays = ANY ? *Q.count * n4 : *Q.count;
 
-    uint32_t w_next = 0, w_end = 0;  // this wave's reserved range of ray indices (wave-uniform)
+    uint32_t r_next = 0, r_end = 0;  // ray indices this wave has reserved (wave-uniform)
+    uint32_t w_next = 0, w_end = 0;  // the range of them it is handing out to its lanes
     uint32_t w_base = 0, cur_slot = 0;  // ANY: first ray and LDS slot of that range
     bool exhausted = false;          // the global queue has no ray left (wave-uniform)
     bool has = false;
@@ -267,14 +276,22 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
                 free_slots = __ballot(lane < kSlots && s_first == kSlotFree);
             }
             if (w_next == w_end && !exhausted && free_slots != 0ull) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(head, kFetchChunk);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (base >= n_rays) {
-                    exhausted = true;
-                } else {
+                if (r_next == r_end) {
+                    uint32_t got = 0;
+                    if (lane == 0) got = atomicAdd(head, kReserve);
+                    got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                    if (got >= n_rays) {
+                        exhausted = true;
+                    } else {
+                        r_next = got;
+                        r_end = min(got + kReserve, n_rays);
+                    }
+                }
+                if (r_next != r_end) {
+                    const uint32_t base = r_next;
                     w_next = base;
-                    w_end = min(base + kFetchChunk, n_rays);
+                    w_end = min(base + kFetchChunk, r_end);
+                    r_next = w_end;
                     if (ANY) {
                         cur_slot = (uint32_t)__builtin_ctzll(free_slots);
                         w_base = base;
@@ -310,7 +327,9 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
                         lim = tmax * tmax;
                         t_max = fsqrt(lim) * 1.000001f;
                     } else {
-                        r = make_ray(Q.ld3(F_RO, ridx), Q.ld3(F_RD, ridx));
+                        const F3 qd = Q.ld3(F_RD, ridx);
+                        take = (qd.x != 0.0f) | (qd.y != 0.0f) | (qd.z != 0.0f);  // a zero direction marks a position without an entry (pt_wfqueue.h: kill_tail)
+                        r = make_ray(Q.ld3(F_RO, ridx), qd);
                         best_t = __builtin_inff();
                         best = -1;
                         out_idx = ridx;
@@ -437,10 +456,12 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
 __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restrict__ blob, Bvh bvh, WfQueue Qin,
                                                  const int *__restrict__ hit_leaf,
                                                  WfQueue Qnext, WfQueue Qshade, float *__restrict__ accum) {
-    __shared__ uint32_t s_cnt[2][4], s_base[2];
+    __shared__ SlabState s_slab;
+    slab_init(&s_slab);
     TblGlobal tbl{blob};
     Tracer<TblGlobal, false, true> tr(P, tbl, bvh, nullptr);
     const uint32_t count = *Qin.count;
+    const uint32_t slab = slab_size(count, gridDim.x);
     const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
     for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
         uint32_t qi = base + threadIdx.x;
@@ -451,9 +472,10 @@ __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restr
         bool scatter = false;
         Rng rng{0u, 1u};
         F3 ro = F3{0, 0, 0}, rd = F3{0, 0, 1}, T = F3{1, 1, 1}, x = F3{0, 0, 0}, nn = F3{0, 1, 0};
+        uint32_t meta = act ? Qin.ldu(U_META, qi) : 0u;
+        act = act && (meta & 1u);  // a position without an entry (the tail of some block's last slab)
         if (act) {
             pix = Qin.ldu(U_PIX, qi);
-            uint32_t meta = Qin.ldu(U_META, qi);
             next = Qin.ldu(U_NEXT, qi);
             depth = (meta >> 1) & 31u;
             media = (int)(meta >> 8) - 1;
@@ -521,7 +543,7 @@ __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restr
             }
         }
         uint32_t pn, ps;
-        queue_reserve2(to_next, Qnext.count, pn, to_shade, Qshade.count, ps, s_cnt, s_base);
+        queue_reserve_slab(to_next, Qnext.count, pn, to_shade, Qshade.count, ps, &s_slab, slab);
         if (to_next) push_ray(Qnext, pn, pix, depth, media, next, ro, rd, T, rng);
         if (to_shade) {
             Qshade.stu(U_PIX, ps, pix);
@@ -536,14 +558,18 @@ __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restr
             Qshade.st3(F_N, ps, nn);
         }
     }
+    kill_tail(Qnext, &s_slab, 0);
+    kill_tail(Qshade, &s_slab, 1);
 }
 
 __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restrict__ blob, WfQueue Qshade,
                                                  const uint32_t *__restrict__ occ_bits,
                                                  WfQueue Qnext, float *__restrict__ accum) {
-    __shared__ uint32_t s_cnt[2][4], s_base[2];
+    __shared__ SlabState s_slab;
+    slab_init(&s_slab);
     TblGlobal tbl{blob};
     const uint32_t count = *Qshade.count;
+    const uint32_t slab = slab_size(count, gridDim.x);
     const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
     for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
         uint32_t qi = base + threadIdx.x;
@@ -553,9 +579,10 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
         int media = -1;
         Rng rng{0u, 1u};
         F3 ro = F3{0, 0, 0}, rd = F3{0, 0, 1}, T = F3{1, 1, 1};
+        uint32_t meta = act ? Qshade.ldu(U_META, qi) : 0u;
+        act = act && (meta & 1u);  // a position without an entry
         if (act) {
             pix = Qshade.ldu(U_PIX, qi);
-            uint32_t meta = Qshade.ldu(U_META, qi);
             next = Qshade.ldu(U_NEXT, qi);
             uint32_t mw = Qshade.ldu(U_MAT, qi);
             rng.s0 = Qshade.ldu(U_RNG0, qi);
@@ -649,9 +676,10 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
             to_next = alive;
         }
         uint32_t pn, unused;
-        queue_reserve2(to_next, Qnext.count, pn, false, nullptr, unused, s_cnt, s_base);
+        queue_reserve_slab(to_next, Qnext.count, pn, false, nullptr, unused, &s_slab, slab);
         if (to_next) push_ray(Qnext, pn, pix, depth, media, next, ro, rd, T, rng);
     }
+    kill_tail(Qnext, &s_slab, 0);
 }
 
 #define WFB_TRAV wfb_traverse
@@ -670,12 +698,16 @@ constexpr uint32_t kWideStackCap = 3u * 48u + 1u;
 size_t wfb_spill_bytes(uint32_t stack_entries) {
     return stack_entries > kLdsEntriesMax ? (size_t)(stack_entries - kLdsEntriesMax) * kGridTrav * kTravThreads * 4 : 256;
 }
+// blocks of the logic / shading kernels for n entries, and the queue positions those entries may occupy (pt_wfqueue.h: slabs)
+unsigned wfb_queue_blocks(uint32_t n) { return std::min((n + 255u) / 256u, 256u * 8u); }
+size_t wfb_positions(uint32_t n) { return (size_t)n + slab_slack(n, wfb_queue_blocks(n)); }
 WfbLayout wfb_layout(uint32_t n, uint32_t n_light) {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     WfbLayout L;
-    L.per_queue = al(queue_bytes(n));
-    L.hits = al((size_t)n * 4);                                          // closest rays: the sphere, 4 bytes
-    L.occ = al((size_t)n * 4 * std::max(1u, n_light) / 8 + 64);          // shadow rays: one bit each, written 32 bytes at a time
+    const size_t np = wfb_positions(n);
+    L.per_queue = al(queue_bytes(np));
+    L.hits = al(np * 4);                                          // closest rays: the sphere, 4 bytes
+    L.occ = al(np * 4 * std::max(1u, n_light) / 8 + 64);          // shadow rays: one bit each, written 32 bytes at a time
     L.total = 4096 + 3 * L.per_queue + L.hits + L.occ;
     return L;
 }
@@ -688,6 +720,10 @@ bool wfb_supports(const BvhBuffers &b) {
 }
 uint32_t wfb_stack_entries(const BvhBuffers &b) { return std::max(8u, 3u * b.wide_levels + 1u); }
 
+// ray ids are 32-bit, and the fetch head runs past the last ray by up to one reservation per wave
+constexpr uint64_t kMaxRayIds = (1ull << 32) - (1ull << 27);
+uint64_t wfb_max_ray_ids() { return kMaxRayIds; }
+
 // room for one pipeline over n entries or two over n / 2 each
 size_t wfb_workspace_bytes(uint32_t n_pixels, uint32_t n_light) {
     return std::max(wfb_layout(n_pixels, n_light).total, 2 * wfb_layout((n_pixels + 1) / 2, n_light).total) +
@@ -698,7 +734,7 @@ uint32_t wfb_streams_log2(uint32_t n_pixels, uint32_t sample_count, uint32_t n_l
     uint32_t lg = 0;
     while (lg < WFB_MAX_STREAMS_LOG2 && ((uint64_t)n_pixels << (lg + 1)) <= (1ull << WFB_INFLIGHT_LOG2) && (2u << lg) <= sample_count &&
            wfb_layout(n_pixels << (lg + 1), n_light).total <= ((unsigned long long)WFB_QUEUE_CAP_GIB << 30) &&
-           ((uint64_t)n_pixels << (lg + 1)) * 4u * std::max(1u, n_light) < (1ull << 32))  // shadow-ray ids k * cap + e are 32-bit
+           wfb_positions(n_pixels << (lg + 1)) * 4u * std::max(1u, n_light) < kMaxRayIds)  // shadow-ray ids e * 4 L + k are 32-bit
         ++lg;
     return lg;
 }
@@ -758,7 +794,8 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
     }
 
     const unsigned blocks_all = (n + 255) / 256;
-    const unsigned grid = std::min(blocks_all, 256u * 8u);
+    const unsigned grid = wfb_queue_blocks(n);
+    if (wfb_positions(n) * 4u * std::max(1u, P.n_light) >= kMaxRayIds) return hipErrorInvalidValue;
     const unsigned grid_trav = kGridTrav;
     if (stack_entries > kWideStackCap || !bvh.wide || (uint64_t)bvh.n + bvh.n_wide > (1ull << 24)) return hipErrorInvalidValue;  // wfb_supports()
     const uint32_t n_top = std::min(bvh.n_wide, kWideTop);

@@ -71,4 +71,84 @@ __device__ __forceinline__ void queue_reserve2(bool want0, uint32_t *count0, uin
     __syncthreads();  // s_cnt / s_base are reused by the next trip
 }
 
+// ---- appends through per-block slabs (LBVH pipeline) ---------------------------------------------------------------
+// queue_reserve2 costs one atomic on the queue's counter per block trip, i.e. per 256 entries, and same-address
+// atomics complete one every ~8-9 ns chip-wide: with 2^27 entries per round the logic kernel's two counters alone
+// were ~150 ms of a C4 step (profiles/r03_c4_wide64_*: the queue kernels streamed at < 2 TB/s). Here a block takes
+// queue positions a SLAB at a time (one atomic per slab of 256..2048 entries) and hands them out from LDS; a trip
+// that outgrows the current slab fills its tail and continues in a new one, so the only unused positions are the
+// tail of each block's last slab, which the block marks dead (kill_tail) before it leaves: consumers skip entries
+// whose alive bit is clear. A queue's `count` is therefore its number of POSITIONS, a few per cent above its entries.
+struct SlabState {
+    uint32_t pos[2], end[2];      // the block's current slab per output queue
+    uint32_t a[2], split[2], b[2];  // this trip: ranks below split sit at a + rank, the others at b + rank - split
+    uint32_t cnt[2][4];
+};
+constexpr uint32_t kSlabMin = 256, kSlabMax = 2048;
+// slab size for a kernel whose input queue holds `count_in` positions: about an eighth of a block's share
+__host__ __device__ inline uint32_t slab_size(uint32_t count_in, uint32_t blocks) {
+    uint32_t s = kSlabMin;
+    while (s < kSlabMax && (uint64_t)s * 2u * blocks * 8u <= count_in) s *= 2u;
+    return s;
+}
+// positions a queue may need beyond its entries: every block of the (at most two) kernels that append to it leaves one slab tail
+// (a round's input may itself hold up to 3 n positions, hence the slab size of 3 n)
+__host__ __device__ inline size_t slab_slack(size_t n, uint32_t blocks) {
+    return 2 * (size_t)blocks * slab_size((uint32_t)(n * 3 < 0xffffffffull ? n * 3 : 0xffffffffull), blocks);
+}
+
+__device__ __forceinline__ void slab_init(SlabState *S) {
+    if (threadIdx.x < 2) S->pos[threadIdx.x] = S->end[threadIdx.x] = 0u;
+    __syncthreads();
+}
+// Every thread of the block must call it. Returns this lane's position in queue 0 / queue 1.
+__device__ __forceinline__ void queue_reserve_slab(bool want0, uint32_t *count0, uint32_t &pos0, bool want1, uint32_t *count1,
+                                                   uint32_t &pos1, SlabState *S, uint32_t slab) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long m0 = __ballot(want0), m1 = __ballot(want1);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) {
+        S->cnt[0][wave] = (uint32_t)__popcll(m0);
+        S->cnt[1][wave] = (uint32_t)__popcll(m1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const uint32_t q = threadIdx.x;
+        uint32_t *cnt = q == 0 ? count0 : count1;
+        const uint32_t tot = S->cnt[q][0] + S->cnt[q][1] + S->cnt[q][2] + S->cnt[q][3];
+        const uint32_t pos = S->pos[q], room = S->end[q] - pos;
+        S->a[q] = pos;
+        if (tot <= room || !cnt) {
+            S->split[q] = tot;
+            S->b[q] = 0u;
+            S->pos[q] = pos + tot;
+        } else {  // tot <= 256 <= slab: one new slab is enough
+            const uint32_t nb = atomicAdd(cnt, slab);
+            S->split[q] = room;
+            S->b[q] = nb;
+            S->pos[q] = nb + (tot - room);
+            S->end[q] = nb + slab;
+        }
+    }
+    __syncthreads();
+    uint32_t r0 = (uint32_t)__popcll(m0 & below), r1 = (uint32_t)__popcll(m1 & below);
+    for (uint32_t w = 0; w < wave; ++w) {
+        r0 += S->cnt[0][w];
+        r1 += S->cnt[1][w];
+    }
+    pos0 = r0 < S->split[0] ? S->a[0] + r0 : S->b[0] + (r0 - S->split[0]);
+    pos1 = r1 < S->split[1] ? S->a[1] + r1 : S->b[1] + (r1 - S->split[1]);
+    __syncthreads();  // the trip's fields are reused by the next trip
+}
+// The unused tail of the block's last slab of output queue q: alive bit clear (the logic / shading kernels skip the
+// entry), zero direction (the closest-hit traversal skips it) and zero normal (every light sample of the any-hit
+// traversal "faces away" and is dropped).
+__device__ __forceinline__ void kill_tail(const WfQueue &Q, const SlabState *S, int q) {
+    for (uint32_t i = S->pos[q] + threadIdx.x; i < S->end[q]; i += blockDim.x) {
+        Q.stu(U_META, i, 0u);
+        Q.st3(F_RD, i, F3{0.0f, 0.0f, 0.0f});
+        Q.st3(F_N, i, F3{0.0f, 0.0f, 0.0f});
+    }
+}
+
 }  // namespace pt
