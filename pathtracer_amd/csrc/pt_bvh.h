@@ -117,6 +117,20 @@ __device__ __forceinline__ float slot_entry(const BoxRay &b, uint4 q, float t_ma
     return box_entry(b, F3{lo16(q.x), hi16(q.x), lo16(q.y)}, F3{hi16(q.y), lo16(q.z), hi16(q.z)}, t_max);
 }
 
+// The same test, returning whether the box is entered and the entry distance separately (one compare and no select
+// fewer than going through +inf).
+__device__ __forceinline__ bool slot_hit(const BoxRay &b, uint4 q, float t_max, float &t_entry) {
+    auto lo16 = [](uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v & 0xffffu)); };
+    auto hi16 = [](uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16)); };
+    const F3 c = F3{lo16(q.x), hi16(q.x), lo16(q.y)}, h = F3{hi16(q.y), lo16(q.z), hi16(q.z)};
+    const float cx = fmaf(c.x, b.slope.x, b.off.x), cy = fmaf(c.y, b.slope.y, b.off.y), cz = fmaf(c.z, b.slope.z, b.off.z);
+    const float nx = fmaf(-h.x, b.aslope.x, cx), fx = fmaf(h.x, b.aslope.x, cx);
+    const float ny = fmaf(-h.y, b.aslope.y, cy), fy = fmaf(h.y, b.aslope.y, cy);
+    const float nz = fmaf(-h.z, b.aslope.z, cz), fz = fmaf(h.z, b.aslope.z, cz);
+    t_entry = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+    return t_entry <= fminf(fminf(fx, fy), fminf(fz, t_max));
+}
+
 // Closest sphere hit. best_t/best_leaf/best_ord are updated in place (start: inf, -1, ~0u).
 // stack: this lane's LDS column, element k at stack[k * stride].
 __device__ __forceinline__ void bvh_closest(const Bvh &B, const RayK &r, float &best_t, int &best_leaf,

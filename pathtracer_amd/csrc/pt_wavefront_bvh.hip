@@ -251,10 +251,13 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
         atomicSub(&wsa[s * kSlotWords + 8], 1u);
     };
 
+    // Two nested loops: the outer one hands rays to idle lanes, the inner one runs trips until kFetchMin lanes are idle
+    // again. (As ONE loop with the refill under `if (n_idle >= kFetchMin)` the compiler copied the ~22 registers of
+    // per-ray state through temporaries on every pass through that block: a third of the kernel's VALU instructions.)
     for (;;) {
-        const unsigned long long idle = __ballot(!has);
+        const unsigned long long idle = ballot64(!has);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
-        if (n_idle >= kFetchMin) {
+        {
             unsigned long long free_slots = 1ull;
             if (ANY) {  // complete ranges go out as 32 bytes of bits and give their slot back
                 uint32_t s_rem = 1u, s_first = kSlotFree;
@@ -350,13 +353,13 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
                 break;
             }
         }
-        if (!has) continue;
-
+        do {
+        if (has) {
         // ---- one item: fetch ----
         const uint32_t u = cur & idx_mask;
         const bool is_leaf = u < bvh.n;
         const uint32_t w = u - bvh.n;
-        uint4 q0, q1 = uint4{0, 0, 0, 0}, q2 = q1, q3 = q1;
+        uint4 q0, q1, q2, q3;  // (q1..q3 are read on the node path only)
         if (!is_leaf && w < n_top) {
             q0 = s_top[w * 4u + 0u], q1 = s_top[w * 4u + 1u], q2 = s_top[w * 4u + 2u], q3 = s_top[w * 4u + 3u];
             if (STATS) ++st_top;
@@ -395,8 +398,9 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
             if (STATS) ++st_nodes;
             const float bound = ANY ? t_max : best_t;  // inclusive: a sphere that ties must still be visited
             auto key = [&](uint4 q) {
-                const float t = slot_entry(br, q, bound);
-                return t < __builtin_inff() ? (((__float_as_uint(t) << 1) & ~idx_mask) | q.w) : kKeyNone;
+                float t;
+                const bool hit = slot_hit(br, q, bound, t);
+                return hit ? (((__float_as_uint(t) << 1) & ~idx_mask) | q.w) : kKeyNone;
             };
             uint32_t k0 = key(q0), k1 = key(q1), k2 = key(q2), k3 = key(q3);
             if (ANY && !WFB_ANY_NEAR_FIRST) {  // experiment: shadow rays in slot order (entered children first, unsorted)
@@ -441,6 +445,8 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
             }
         }
         if (finished) has = false;
+        }
+        } while ((uint32_t)__popcll(ballot64(!has)) < kFetchMin);
     }
     if (STATS) {
         uint32_t v[5] = {st_rays, st_nodes, st_leaves, st_aux, st_top};
