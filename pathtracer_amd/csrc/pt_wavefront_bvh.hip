@@ -117,6 +117,32 @@ __device__ __forceinline__ void light_sample(float4 l0, float4 l1, float4 l2, F3
     inv_d2 = inv * inv;
 }
 
+// renderer.rs:49-55: a light sample contributes only if the surface faces it and it faces the surface. wfb_logic
+// (which lists the shadow rays to trace) and wfb_shade (which looks their results up) must decide alike.
+__device__ __forceinline__ bool sample_faces(F3 nn, F3 l, float4 l4) { return (dot(nn, l) > 0.0f) & (-dot(l, f3(l4)) > 0.0f); }
+// The 4 L light samples of a vertex in draw order (renderer.rs:35-39): f(k, l, tmax, inv_d2, faces) for k = 0 .. 4L-1.
+// `rng` advances by the 8 L draws.
+template <class F>
+__device__ __forceinline__ void for_each_light_sample(const TblGlobal &tbl, const Params &P, Rng &rng, F3 x, F3 nn, F f) {
+    for (uint32_t li = 0; li < P.n_light; ++li) {
+        const uint32_t o = P.light_off + li * LIGHT_F4;
+        const float4 l0 = tbl.ld(o), l1 = tbl.ld(o + 1), l2 = tbl.ld(o + 2), l4 = tbl.ld(o + 4);
+#pragma unroll
+        for (uint32_t s = 0; s < 4u; ++s) {
+            const float e1 = rng.gen() - 0.5f;
+            const float e2 = rng.gen() - 0.5f;
+            F3 l;
+            float tmax, inv_d2;
+            light_sample(l0, l1, l2, x, e1, e2, l, tmax, inv_d2);
+            f(li * 4u + s, l, tmax, inv_d2, sample_faces(nn, l, l4));
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t slab_item_of(uint32_t a, uint32_t split, uint32_t b, uint32_t rank) {
+    return rank < split ? a + rank : b + (rank - split);
+}
+
 // Every stream starts with the camera path of its first sample; entries of the ray queue are always live rays.
 // The streams of a launch are dealt to 2^group_bits groups (the host's concurrent pipelines); group g owns the streams
 // whose top group_bits bits are g, and entry j of its queue is (pixel, stream) = (j >> (k - group_bits), g's j-th stream).
@@ -199,7 +225,8 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
                                                     const uint32_t *__restrict__ jump,
                                                     uint32_t *__restrict__ head,
                                                     int *__restrict__ hit_leaf,
-                                                    uint32_t *__restrict__ occ_bits, unsigned long long *__restrict__ stats,
+                                                    uint32_t *__restrict__ occ_bits, const uint32_t *__restrict__ ray_ids,
+                                                    const uint32_t *__restrict__ ray_count, unsigned long long *__restrict__ stats,
                                                     uint32_t lds_entries, uint32_t *__restrict__ spill, uint32_t idx_bits, uint32_t n_top,
                                                     uint32_t light_off = 0, uint32_t n_light = 0) {
     uint32_t st_rays = 0, st_nodes = 0, st_leaves = 0, st_aux = 0, st_top = 0;
@@ -229,7 +256,7 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
     // kernel, no sample buffer and no ray list.
     const uint32_t n4 = 4u * n_light;
     const uint32_t n4_shift = (n4 & (n4 - 1u)) == 0u ? (uint32_t)__builtin_ctz(n4 | 0x80000000u) : 0xffffffffu;
-    const uint32_t n_rays = ANY ? *Q.count * n4 : *Q.count;
+    const uint32_t n_rays = ANY ? *ray_count : *Q.count;
 
     uint32_t r_next = 0, r_end = 0;  // ray indices this wave has reserved (wave-uniform)
     uint32_t w_next = 0, w_end = 0;  // the range of them it is handing out to its lanes
@@ -311,20 +338,23 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
                     uint32_t ridx = w_next + rank;
                     bool take = true;
                     if (ANY) {
-                        const uint32_t e = n4_shift != 0xffffffffu ? ridx >> n4_shift : ridx / n4, k = ridx - e * n4;
+                        // shadow ray `ridx` of the list wfb_logic wrote: sample id e * 4 L + k of a sample that faces its light
+                        const uint32_t sid = ray_ids[ridx];
+                        take = sid != 0xffffffffu;  // (the unused tail of a block's last slab of the list)
+                        const uint32_t sidc = take ? sid : 0u;
+                        const uint32_t e = n4_shift != 0xffffffffu ? sidc >> n4_shift : sidc / n4, k = sidc - e * n4;
                         const float4 *lrow = blob + light_off + (k >> 2) * LIGHT_F4;
-                        const float4 l0 = lrow[0], l1 = lrow[1], l2 = lrow[2], l4 = lrow[4];
+                        const float4 l0 = lrow[0], l1 = lrow[1], l2 = lrow[2];
                         const uint32_t ja = jump[2u * k], jc = jump[2u * k + 1u];
                         const uint32_t s0 = Q.ldu(U_RNG0, e), inc = Q.ldu(U_RNG1, e);
                         Rng rg{s0 * ja + inc * jc, inc};
                         const float e1 = rg.gen() - 0.5f;
                         const float e2 = rg.gen() - 0.5f;
-                        const F3 x = Q.ld3(F_X, e), nn = Q.ld3(F_N, e);
+                        const F3 x = Q.ld3(F_X, e);
                         F3 l;
                         float tmax, inv_d2;
                         light_sample(l0, l1, l2, x, e1, e2, l, tmax, inv_d2);
                         out_idx = (cur_slot << 8) | (ridx - w_base);
-                        take = (dot(nn, l) > 0.0f) & (-dot(l, f3(l4)) > 0.0f);
                         if (!take) settle(out_idx, true);
                         r = make_ray(madd(x, l, 1e-4f), l);
                         lim = tmax * tmax;
@@ -461,13 +491,15 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
 // Everything of one path vertex that follows the closest-sphere query and precedes next-event estimation.
 __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restrict__ blob, Bvh bvh, WfQueue Qin,
                                                  const int *__restrict__ hit_leaf,
-                                                 WfQueue Qnext, WfQueue Qshade, float *__restrict__ accum) {
+                                                 WfQueue Qnext, WfQueue Qshade, float *__restrict__ accum,
+                                                 uint32_t *__restrict__ ray_ids, uint32_t *__restrict__ ray_count) {
     __shared__ SlabState s_slab;
     slab_init(&s_slab);
     TblGlobal tbl{blob};
     Tracer<TblGlobal, false, true> tr(P, tbl, bvh, nullptr);
     const uint32_t count = *Qin.count;
     const uint32_t slab = slab_size(count, gridDim.x);
+    const uint32_t slab_ids = ids_slab_size(slab, P.n_light);
     const uint32_t seed_mixed = mix32(P.seed ^ 0x85ebca6bu);
     for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
         uint32_t qi = base + threadIdx.x;
@@ -550,8 +582,34 @@ __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restr
         }
         uint32_t pn, ps;
         queue_reserve_slab(to_next, Qnext.count, pn, to_shade, Qshade.count, ps, &s_slab, slab);
+        // The shadow rays of the vertex: the light samples that face their light (renderer.rs:49-55; half of C4's do
+        // not), listed by sample id for wfb_traverse<ANY>, vertex by vertex. This kernel waits on memory, so drawing
+        // the samples here costs nothing, whereas a traversal lane that drew a sample only to drop it stood idle
+        // until its wave's next refill. The samples are drawn twice (count, then write) rather than kept.
+        uint32_t n_face = 0u;
+        if (to_shade) {
+            Rng rc = rng;
+            for_each_light_sample(tbl, P, rc, x, nn, [&](uint32_t, F3, float, float, bool faces) { n_face += faces ? 1u : 0u; });
+        }
+        const uint32_t first_ray = list_reserve_slab(n_face, ray_count, &s_slab, slab_ids);
+        if (n_face) {
+            Rng rc = rng;
+            uint32_t j = first_ray;
+            const uint32_t sid0 = ps * (4u * P.n_light);
+            for_each_light_sample(tbl, P, rc, x, nn, [&](uint32_t k, F3, float, float, bool faces) {
+                if (faces) ray_ids[slab_item(&s_slab, j++)] = sid0 + k;
+            });
+        }
+        const uint32_t s_slab_a = s_slab.a[2], s_slab_split = s_slab.split[2], s_slab_b = s_slab.b[2];
+        __syncthreads();  // the list allocator's fields are reused by the next trip
         if (to_next) push_ray(Qnext, pn, pix, depth, media, next, ro, rd, T, rng);
         if (to_shade) {
+            // where the results of the vertex's shadow rays will be: list positions p_first .. p_first + seg - 1, then
+            // (a vertex whose rays straddle two slabs) p_second ..
+            const uint32_t split = s_slab_split, seg = first_ray >= split ? n_face : min(n_face, split - first_ray);
+            Qshade.stw(F_SUM + 0, ps, slab_item_of(s_slab_a, split, s_slab_b, first_ray));
+            Qshade.stw(F_SUM + 1, ps, seg);
+            Qshade.stw(F_SUM + 2, ps, s_slab_b);
             Qshade.stu(U_PIX, ps, pix);
             Qshade.stu(U_META, ps, 1u | (depth << 1) | (scatter ? 64u : 0u) | ((uint32_t)(media + 1) << 8));
             Qshade.stu(U_NEXT, ps, next);
@@ -566,6 +624,7 @@ __global__ __launch_bounds__(256) void wfb_logic(Params P, const float4 *__restr
     }
     kill_tail(Qnext, &s_slab, 0);
     kill_tail(Qshade, &s_slab, 1);
+    for (uint32_t i = s_slab.pos[2] + threadIdx.x; i < s_slab.end[2]; i += blockDim.x) ray_ids[i] = 0xffffffffu;  // no ray
 }
 
 __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restrict__ blob, WfQueue Qshade,
@@ -605,6 +664,8 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
             ShadeK sk = make_shade(nn, -rd, m);
 
             // pt_trace.h: direct_light, with the samples and their sphere occlusion already computed
+            const uint32_t p_first = Qshade.ldw(F_SUM + 0, qi), seg = Qshade.ldw(F_SUM + 1, qi), p_second = Qshade.ldw(F_SUM + 2, qi);
+            uint32_t n_seen = 0u;  // facing samples so far: the j-th one's result is the j-th of the vertex's list positions
             F3 total = F3{0.0f, 0.0f, 0.0f};
             for (uint32_t li = 0; li < P.n_light; ++li) {
                 uint32_t o = P.light_off + li * LIGHT_F4;
@@ -617,8 +678,12 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
                     float e1 = rng.gen() - 0.5f;
                     float e2 = rng.gen() - 0.5f;
                     light_sample(l0, l1, l2, x, e1, e2, l[s], tmax[s], id2[s]);
-                    const uint32_t rbit = qi * (4u * P.n_light) + li * 4u + (uint32_t)s;  // wfb_traverse<ANY>: ray e * 4 L + k
-                    occ[s] = ((occ_bits[rbit >> 5] >> (rbit & 31u)) & 1u) != 0u;
+                    occ[s] = true;  // a sample that faces away needs no ray and adds nothing (renderer.rs:49-55)
+                    if (sample_faces(nn, l[s], l4)) {
+                        const uint32_t rbit = n_seen < seg ? p_first + n_seen : p_second + (n_seen - seg);
+                        ++n_seen;
+                        occ[s] = ((occ_bits[rbit >> 5] >> (rbit & 31u)) & 1u) != 0u;
+                    }
                 }
                 uint32_t c0 = 0, c1 = 0;
                 occluded_multi<TblGlobal, 4, false>(tbl, P, x, 1e-4f, l, tmax, occ, c0, c1, false);
@@ -693,7 +758,7 @@ __global__ __launch_bounds__(256) void wfb_shade(Params P, const float4 *__restr
 // ---- host driver -----------------------------------------------------------------------
 namespace {
 struct WfbLayout {
-    size_t per_queue, hits, occ, total;
+    size_t per_queue, hits, occ, ids, total;
 };
 constexpr unsigned kGridTrav = 256u * 8u * 256u / kTravThreads;  // persistent traversal blocks: every CU full
 // stack entries in LDS with 8 blocks per CU: what is left of 20 KB beside the first kWideTop wide nodes and the range slots (13 for 85 nodes)
@@ -707,14 +772,21 @@ size_t wfb_spill_bytes(uint32_t stack_entries) {
 // blocks of the logic / shading kernels for n entries, and the queue positions those entries may occupy (pt_wfqueue.h: slabs)
 unsigned wfb_queue_blocks(uint32_t n) { return std::min((n + 255u) / 256u, 256u * 8u); }
 size_t wfb_positions(uint32_t n) { return (size_t)n + slab_slack(n, wfb_queue_blocks(n)); }
+// positions the list may occupy: every sample of every entry plus one slab tail per block
+size_t wfb_ray_positions(uint32_t n, uint32_t n_light) {
+    const unsigned blocks = wfb_queue_blocks(n);
+    return wfb_positions(n) * 4 * std::max(1u, n_light) + (size_t)blocks * ids_slab_size(kSlabMax, n_light);
+}
 WfbLayout wfb_layout(uint32_t n, uint32_t n_light) {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     WfbLayout L;
     const size_t np = wfb_positions(n);
     L.per_queue = al(queue_bytes(np));
     L.hits = al(np * 4);                                          // closest rays: the sphere, 4 bytes
-    L.occ = al(np * 4 * std::max(1u, n_light) / 8 + 64);          // shadow rays: one bit each, written 32 bytes at a time
-    L.total = 4096 + 3 * L.per_queue + L.hits + L.occ;
+    const size_t nr = wfb_ray_positions(n, n_light);
+    L.occ = al(nr / 8 + 64);                                      // shadow rays: one bit each, written 32 bytes at a time
+    L.ids = al(nr * 4);                                           // the list of shadow rays (sample ids)
+    L.total = 4096 + 3 * L.per_queue + L.hits + L.occ + L.ids;
     return L;
 }
 }  // namespace
@@ -740,7 +812,7 @@ uint32_t wfb_streams_log2(uint32_t n_pixels, uint32_t sample_count, uint32_t n_l
     uint32_t lg = 0;
     while (lg < WFB_MAX_STREAMS_LOG2 && ((uint64_t)n_pixels << (lg + 1)) <= (1ull << WFB_INFLIGHT_LOG2) && (2u << lg) <= sample_count &&
            wfb_layout(n_pixels << (lg + 1), n_light).total <= ((unsigned long long)WFB_QUEUE_CAP_GIB << 30) &&
-           wfb_positions(n_pixels << (lg + 1)) * 4u * std::max(1u, n_light) < kMaxRayIds)  // shadow-ray ids e * 4 L + k are 32-bit
+           wfb_ray_positions(n_pixels << (lg + 1), n_light) < kMaxRayIds)  // shadow-ray ids e * 4 L + k are 32-bit
         ++lg;
     return lg;
 }
@@ -772,6 +844,7 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
         WfQueue Q[3];
         int *hit_leaf;
         uint32_t *occ;
+        uint32_t *ids;
         uint32_t *spill;
         bool done;
     } G[2];
@@ -796,12 +869,14 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
         G[g].hit_leaf = (int *)w;
         w += L.hits;
         G[g].occ = (uint32_t *)w;
+        w += L.occ;
+        G[g].ids = (uint32_t *)w;
         G[g].done = false;
     }
 
     const unsigned blocks_all = (n + 255) / 256;
     const unsigned grid = wfb_queue_blocks(n);
-    if (wfb_positions(n) * 4u * std::max(1u, P.n_light) >= kMaxRayIds) return hipErrorInvalidValue;
+    if (wfb_ray_positions(n, P.n_light) >= kMaxRayIds) return hipErrorInvalidValue;
     const unsigned grid_trav = kGridTrav;
     if (stack_entries > kWideStackCap || !bvh.wide || (uint64_t)bvh.n + bvh.n_wide > (1ull << 24)) return hipErrorInvalidValue;  // wfb_supports()
     const uint32_t n_top = std::min(bvh.n_wide, kWideTop);
@@ -847,23 +922,23 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
             hipStream_t s = A.st;
             uint32_t *counters = A.counters;
             if ((e = hipMemsetAsync(&counters[1 - cur], 0, 4, s)) != hipSuccess) return join(e);
-            if ((e = hipMemsetAsync(&counters[2], 0, 16, s)) != hipSuccess) return join(e);  // shade count, both fetch heads
+            if ((e = hipMemsetAsync(&counters[2], 0, 16, s)) != hipSuccess) return join(e);  // shade count, both fetch heads, shadow-ray count
             if (stats)
                 hipLaunchKernelGGL((WFB_TRAV<false, true>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[cur], (const float4 *)nullptr,
-                                   (const uint32_t *)nullptr, &counters[3], A.hit_leaf, (uint32_t *)nullptr, stats, lds_entries, A.spill, idx_bits, n_top);
+                                   (const uint32_t *)nullptr, &counters[3], A.hit_leaf, (uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, stats, lds_entries, A.spill, idx_bits, n_top);
             else
                 hipLaunchKernelGGL((WFB_TRAV<false, false>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[cur], (const float4 *)nullptr,
-                                   (const uint32_t *)nullptr, &counters[3], A.hit_leaf, (uint32_t *)nullptr,
+                                   (const uint32_t *)nullptr, &counters[3], A.hit_leaf, (uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
                                    (unsigned long long *)nullptr, lds_entries, A.spill, idx_bits, n_top);
             hipLaunchKernelGGL(wfb_logic, dim3(grid), dim3(256), 0, s, P, blob, bvh, A.Q[cur],
-                               (const int *)A.hit_leaf, A.Q[1 - cur], A.Q[2], sums);
+                               (const int *)A.hit_leaf, A.Q[1 - cur], A.Q[2], sums, A.ids, &counters[5]);
             if (stats)
                 hipLaunchKernelGGL((WFB_TRAV<true, true>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[2], blob,
-                                   (const uint32_t *)(counters + 256), &counters[4], (int *)nullptr, A.occ,
+                                   (const uint32_t *)(counters + 256), &counters[4], (int *)nullptr, A.occ, (const uint32_t *)A.ids, (const uint32_t *)&counters[5],
                                    stats, lds_entries, A.spill, idx_bits, n_top, P.light_off, P.n_light);
             else
                 hipLaunchKernelGGL((WFB_TRAV<true, false>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[2], blob,
-                                   (const uint32_t *)(counters + 256), &counters[4], (int *)nullptr, A.occ,
+                                   (const uint32_t *)(counters + 256), &counters[4], (int *)nullptr, A.occ, (const uint32_t *)A.ids, (const uint32_t *)&counters[5],
                                    (unsigned long long *)nullptr, lds_entries, A.spill, idx_bits, n_top, P.light_off, P.n_light);
             hipLaunchKernelGGL(wfb_shade, dim3(grid), dim3(256), 0, s, P, blob, A.Q[2], (const uint32_t *)A.occ,
                                A.Q[1 - cur], sums);

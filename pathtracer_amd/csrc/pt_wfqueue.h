@@ -37,6 +37,9 @@ struct WfQueue {
         p[kQueueTile] = v.y;
         p[2 * kQueueTile] = v.z;
     }
+    // a uint kept in one of the float planes (F_SUM is free in the LBVH pipeline's shade entries)
+    __device__ __forceinline__ uint32_t ldw(int k, uint32_t i) const { return __float_as_uint(f[at(k, i)]); }
+    __device__ __forceinline__ void stw(int k, uint32_t i, uint32_t v) const { f[at(k, i)] = __uint_as_float(v); }
     __device__ __forceinline__ uint32_t ldu(int k, uint32_t i) const { return __float_as_uint(f[at(NF + k, i)]); }
     __device__ __forceinline__ void stu(int k, uint32_t i, uint32_t v) const { f[at(NF + k, i)] = __uint_as_float(v); }
 };
@@ -80,9 +83,9 @@ __device__ __forceinline__ void queue_reserve2(bool want0, uint32_t *count0, uin
 // tail of each block's last slab, which the block marks dead (kill_tail) before it leaves: consumers skip entries
 // whose alive bit is clear. A queue's `count` is therefore its number of POSITIONS, a few per cent above its entries.
 struct SlabState {
-    uint32_t pos[2], end[2];      // the block's current slab per output queue
-    uint32_t a[2], split[2], b[2];  // this trip: ranks below split sit at a + rank, the others at b + rank - split
-    uint32_t cnt[2][4];
+    uint32_t pos[3], end[3];      // the block's current slab per output queue ([2]: the shadow-ray id list)
+    uint32_t a[3], split[3], b[3];  // this trip: ranks below split sit at a + rank, the others at b + rank - split
+    uint32_t cnt[3][4];
 };
 constexpr uint32_t kSlabMin = 256, kSlabMax = 2048;
 // slab size for a kernel whose input queue holds `count_in` positions: about an eighth of a block's share
@@ -97,9 +100,49 @@ __host__ __device__ inline size_t slab_slack(size_t n, uint32_t blocks) {
     return 2 * (size_t)blocks * slab_size((uint32_t)(n * 3 < 0xffffffffull ? n * 3 : 0xffffffffull), blocks);
 }
 
+// slab of the shadow-ray list (list_reserve_slab): a block trip appends up to 256 x 4 L ids
+__host__ __device__ inline uint32_t ids_slab_size(uint32_t slab, uint32_t n_light) {
+    return slab * 4u > 1024u * n_light ? slab * 4u : 1024u * (n_light ? n_light : 1u);
+}
 __device__ __forceinline__ void slab_init(SlabState *S) {
-    if (threadIdx.x < 2) S->pos[threadIdx.x] = S->end[threadIdx.x] = 0u;
+    if (threadIdx.x < 3) S->pos[threadIdx.x] = S->end[threadIdx.x] = 0u;
     __syncthreads();
+}
+// Third allocator, for lists in which a lane appends n >= 0 consecutive items (the shadow-ray ids of its vertex):
+// returns the position of the lane's first item; item j of the lane sits at slab_item(S, first + j).
+// `slab` must be at least the largest total a trip can ask for. Every thread of the block must call it.
+__device__ __forceinline__ uint32_t list_reserve_slab(uint32_t n, uint32_t *count, SlabState *S, uint32_t slab) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = n;  // inclusive prefix sum over the wave
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if (lane >= (uint32_t)off) incl += v;
+    }
+    if (lane == 63u) S->cnt[2][wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = S->cnt[2][0] + S->cnt[2][1] + S->cnt[2][2] + S->cnt[2][3];
+        const uint32_t pos = S->pos[2], room = S->end[2] - pos;
+        S->a[2] = pos;
+        if (tot <= room) {
+            S->split[2] = tot;
+            S->b[2] = 0u;
+            S->pos[2] = pos + tot;
+        } else {
+            const uint32_t nb = atomicAdd(count, slab);
+            S->split[2] = room;
+            S->b[2] = nb;
+            S->pos[2] = nb + (tot - room);
+            S->end[2] = nb + slab;
+        }
+    }
+    __syncthreads();
+    uint32_t first = incl - n;
+    for (uint32_t w = 0; w < wave; ++w) first += S->cnt[2][w];
+    return first;  // a RANK within this trip's items of the block; slab_item() turns ranks into positions
+}
+__device__ __forceinline__ uint32_t slab_item(const SlabState *S, uint32_t rank) {
+    return rank < S->split[2] ? S->a[2] + rank : S->b[2] + (rank - S->split[2]);
 }
 // Every thread of the block must call it. Returns this lane's position in queue 0 / queue 1.
 __device__ __forceinline__ void queue_reserve_slab(bool want0, uint32_t *count0, uint32_t &pos0, bool want1, uint32_t *count1,
