@@ -449,9 +449,20 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
                 else spill_col[((uint32_t)sp - lds_entries) * spill_stride] = item;
                 ++sp;
             };
-            if (a3 != kKeyNone) push(a3);
-            if (a2 != kKeyNone) push(a2);
-            if (a1 != kKeyNone) push(a1);
+            if (__builtin_expect((uint32_t)sp + 3u <= lds_entries, 1)) {
+                // without branches: each candidate is stored at the running top, which moves on only if it was a real one
+                // (a miss is overwritten by the next store or stays above the top, unused)
+                stack[sp * stride] = a3;
+                sp += a3 != kKeyNone ? 1 : 0;
+                stack[sp * stride] = a2;
+                sp += a2 != kKeyNone ? 1 : 0;
+                stack[sp * stride] = a1;
+                sp += a1 != kKeyNone ? 1 : 0;
+            } else {
+                if (a3 != kKeyNone) push(a3);
+                if (a2 != kKeyNone) push(a2);
+                if (a1 != kKeyNone) push(a1);
+            }
             if (a0 != kKeyNone) cur = a0;
             else need_pop = true;
         }
