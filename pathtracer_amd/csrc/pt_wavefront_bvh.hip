@@ -836,8 +836,11 @@ uint32_t wfb_streams_log2(uint32_t n_pixels, uint32_t sample_count, uint32_t n_l
 // for most of their cycles and leave HBM idle; the logic / shading kernels stream the queues through HBM and
 // leave the vector L1s idle; and every traversal launch ends with a tail in which a few long rays keep a few waves
 // busy. Two independent pipelines let the hardware fill each of these gaps with the other group's kernels.
+// Round 3: OFF by default (WFB_GROUPS = 1). That reasoning held for round 2's traversal kernels (+2.8 %); the 4-wide
+// kernels keep the vector ALUs 85-95 % busy (profiles/r03_c4_*), a second pipeline's kernels only compete with them
+// for issue slots, and one pipeline over all streams is 3.2 % faster (1 087 vs 1 053 Mpaths/s on C4, interleaved A/B).
 #ifndef WFB_GROUPS
-#define WFB_GROUPS 2
+#define WFB_GROUPS 1
 #endif
 hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &bvh, uint32_t stack_entries, float *accum,
                                 void *workspace, hipStream_t st, uint32_t *iterations_out, unsigned long long *stats, float *partial,
