@@ -133,7 +133,20 @@ int pack_scene(const hippt_scene *sc, PackedScene &out) {
     P.light_off = P.mat_off + sc->n_materials * pt::MAT_F4;
     P.cam_off = P.light_off + sc->n_lights * pt::LIGHT_F4;
     P.cull_off = P.cam_off + pt::CAM_F4;
-    P.blob_f4 = P.cull_off + sc->n_lights * sc->n_planes;
+    // The light-side table is n_lights x n_planes words: it pays on small scenes (it is staged in LDS with the other
+    // tables). Beyond kMaxCullEntries all lights share ONE all-zero row ("straddles": never skip), so the table can
+    // neither grow quadratically nor push a scene out of the LDS budget. Sizes are formed in 64 bits (the
+    // 32-bit product wrapped for ~66k lights x ~66k planes and the fill loop then wrote past the blob).
+    constexpr uint64_t kMaxCullEntries = 4096;
+    const uint64_t cull_entries = (uint64_t)sc->n_lights * sc->n_planes;
+    const bool cull_table = cull_entries <= kMaxCullEntries;
+    P.cull_stride = cull_table ? sc->n_planes : 0u;
+    const uint64_t blob_f4 = (uint64_t)P.cull_off + (cull_table ? cull_entries : sc->n_planes);
+    const uint64_t off_check = (uint64_t)sc->n_spheres * 2 + (uint64_t)sc->n_planes * 4 + (uint64_t)sc->n_materials * pt::MAT_F4 +
+                               (uint64_t)sc->n_lights * pt::LIGHT_F4 + pt::CAM_F4;  // the 32-bit offsets above, in 64 bits
+    if (off_check + (cull_table ? cull_entries : sc->n_planes) != blob_f4 || blob_f4 > (1ull << 28))
+        return hippt_set_error(HIPPT_ERR_LIMIT, "scene tables of %llu x 16 bytes exceed 4 GiB", (unsigned long long)(off_check + cull_entries));
+    P.blob_f4 = (uint32_t)blob_f4;
     P.tiles_x = (sc->width + 15u) / 16u;
     out.blob.assign(P.blob_f4, mk4(0, 0, 0, 0));
     {
@@ -198,7 +211,7 @@ int pack_scene(const hippt_scene *sc, PackedScene &out) {
         // Which side of each plane the light's rectangle lies on (pt_device.h: occluded_multi, CULL). Light points are
         // pos + u e1 + v e2 with e in [-1/2, 1/2) (renderer.rs:37-39): the four corners bound (y - p).n. The margin
         // keeps the f32 arithmetic of the kernel (and of the light points it forms) well inside the decision.
-        for (uint32_t k = 0; k < sc->n_planes; ++k) {
+        for (uint32_t k = 0; cull_table && k < sc->n_planes; ++k) {
             const hippt_plane &p = sc->planes[pi[k]];
             double lo = INFINITY, hi = -INFINITY, scale = 0.0;
             for (int c = 0; c < 4; ++c) {

@@ -32,6 +32,7 @@ struct Params {
     uint32_t width, height;
     uint32_t n_sph, n_pl, n_mat, n_light;
     uint32_t sph_off, pl_off, aux_off, mat_off, light_off, cam_off, cull_off;  // float4 offsets into the blob
+    uint32_t cull_stride;         // rows of the cull table per light: n_pl, or 0 when all lights share one all-zero row (table too large to pay)
     uint32_t blob_f4;             // blob size in float4
     uint32_t sample_begin, sample_count, max_depth, seed;
     uint32_t tiles_x;             // 16x16 pixel tiles per row

@@ -123,7 +123,7 @@ struct Tracer {
             }
             occluded_multi<Tbl, 4, COUNT, false, PT_CULL != 0>(tbl, P, x, 1e-4f, l, tmax, occ, cnt[HIPPT_C_SHADOW_SPHERE_TESTS],
                                                        cnt[HIPPT_C_SHADOW_PLANE_TESTS], !BVH, nullptr, nullptr,
-                                                       P.cull_off + li * P.n_pl);
+                                                       P.cull_off + li * P.cull_stride);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (!occ[s]) {
@@ -283,7 +283,7 @@ struct Tracer {
                 bool occ[4];
                 uint32_t dom, dom_lanes;
                 occluded_multi<Tbl, 4, false, true, PT_CULL != 0>(tbl, P, x, 1e-4f, l, tmax, occ, dummy0, dummy1, true, &dom, &dom_lanes,
-                                                          P.cull_off + li * P.n_pl);
+                                                          P.cull_off + li * P.cull_stride);
                 // worth remembering if the lanes it leaves over fit a batch: at most 4 rays each
                 if (li < kHintLights && dom_lanes != 0u && (n_nee - dom_lanes) * 4u <= PT_HINT_SLACK)
                     __hip_atomic_store(&sh->hint[li], dom, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

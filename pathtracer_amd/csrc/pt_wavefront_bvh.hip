@@ -360,6 +360,10 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
                         lim = tmax * tmax;
                         t_max = fsqrt(lim) * 1.000001f;
                     } else {
+                        // (streaming loads here, so that the rays do not displace the result lines a wave is still filling from
+                        // the L2, were measured: the closest-hit launches' writes fall from 2.2x to 1.4x their algorithmic 4 bytes per
+                        // ray, but their fetches double — a wave takes ~20 rays of a 64-ray row per refill and the rest of the line is
+                        // fetched again — and the step time is the same: not adopted, profiles/r03_c4_stream_loads_traffic.txt)
                         const F3 qd = Q.ld3(F_RD, ridx);
                         take = (qd.x != 0.0f) | (qd.y != 0.0f) | (qd.z != 0.0f);  // a zero direction marks a position without an entry (pt_wfqueue.h: kill_tail)
                         r = make_ray(Q.ld3(F_RO, ridx), qd);
