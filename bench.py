@@ -45,7 +45,7 @@ CONFIGS = {
     "c3": (1920, 1080, 4096, "glass_fog.json"),
     "c4": (1920, 1080, 256, None),   # synthetic_spheres(100000, 0x5EED), LBVH
     # the showcase job is 131072 spp (4.3 T paths, ~11 min on one GPU): a step is one 128-spp chunk of it
-    "c5": (7680, 4320, 128, "scene.example.json"),
+    "c5": (7680, 4320, 128, "scene.example.json"),   # "128-spp chunk of C5"
 }
 
 # Counter figures that cannot be read inside this process (rocprofv3 --pmc runs of this same command, kept under
@@ -63,21 +63,52 @@ def pmc_lookup(config, W, H, spp_launch, flags, max_depth):
 
 
 def cpu_baseline(threads):
-    """CPU restatement of the reference renderer (oracle) on the host cores: bounded sample."""
+    """CPU restatement of the reference renderer (oracle source) on the host cores, as SURVEY §8(d) defines the CPU
+    baseline: its own -O3 -march=native build (compiled here, on the machine that times it; the checker library stays
+    -O2), C1 exactly (scene.example.json 320x240x16) plus 1920x1080 (at 64 spp, so that the sample lasts 10-30 s) for a per-path rate comparable with C2.
+    `value` is the 1080p rate."""
+    import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     from pathtracer_amd import Scene
-    orc = oracle_lib.Oracle()
-    spp = 64
-    s = Scene.load(os.path.join(ROOT, "scenes", "scene.example.json"), 1920, 1080, spp)
-    t0 = time.perf_counter()
-    orc.render_accum(s, 0, spp, seed=0, threads=threads)
-    dt = time.perf_counter() - t0
-    return {"value": round(1920 * 1080 * spp / dt / 1e6, 4), "unit": "Mpaths/s", "cores": threads, "kind": "port",
-            "host_cores_online": os.cpu_count(),
-            "sample": f"scene.example.json 1920x1080 at {spp} spp (C2's scene and size, 1/16 of its samples; not C1 + "
-                      f"1080p x 16 as SURVEY §8d sketched), {dt:.1f} s on {threads} threads (the GPU box's CPU share); "
+    try:
+        tmp = tempfile.mkdtemp(prefix="hippt_cpu_baseline_")
+        path, flags = oracle_lib.build_fast_oracle(tmp)
+        orc = oracle_lib.Oracle(path)
+        build = f"g++ {flags}"
+    except Exception as e:  # no compiler on this machine: the checker build, said so
+        orc = oracle_lib.Oracle()
+        build = f"g++ -O2 -ffp-contract=off (checker library; the -O3 -march=native build failed here: {type(e).__name__})"
+    ex = os.path.join(ROOT, "scenes", "scene.example.json")
+    rates = {}
+    # (1080p at 64 spp rather than §8d's 16: the sample should last 10-30 s; 16 spp is 3 s on 16 threads)
+    for name, (w, h, spp) in (("c1_320x240x16", (320, 240, 16)), ("1080p_x64", (1920, 1080, 64))):
+        s = Scene.load(ex, w, h, spp)
+        orc.render_accum(s, 0, 1, seed=0, threads=threads)  # warm the threads / caches
+        t0 = time.perf_counter()
+        orc.render_accum(s, 0, spp, seed=0, threads=threads)
+        dt = time.perf_counter() - t0
+        rates[name] = (w * h * spp / dt / 1e6, dt)
+    v, dt = rates["1080p_x64"]
+    return {"value": round(v, 4), "unit": "Mpaths/s", "cores": threads, "kind": "port",
+            "host_cores_online": os.cpu_count(), "build": build,
+            "c1_mpaths_per_s": round(rates["c1_320x240x16"][0], 4), "c1_seconds": round(rates["c1_320x240x16"][1], 4),
+            "sample": f"scene.example.json at 1920x1080 x 64 spp ({dt:.1f} s; C2's scene and size, 1/16 of its samples) and C1 exactly (320x240 x 16 spp, "
+                      f"{rates['c1_320x240x16'][1]:.2f} s) on {threads} threads (the GPU box's CPU share), SURVEY §8(d); "
                       f"C++ restatement of src/renderer.rs, one task per row as src/main.rs:126"}
+
+
+def csrc_hash():
+    """Hash of the kernel and host sources the library is built from: ties the PMC figures of pmc_index.json to a build."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pathtracer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def parse_args(argv=None):
@@ -278,6 +309,23 @@ def main():
         kernel = (("wavefront+lbvh" if not args.flags & _abi.FLAG_MEGAKERNEL else "megakernel+lbvh") if lbvh else
                   ("wavefront" if args.flags & _abi.FLAG_WAVEFRONT else "megakernel"))
         pmc = pmc_lookup(args.config if not args.scene else "scene", W, H, cnt // launches_per_step, args.flags, args.max_depth)
+        # SURVEY §8(d) credits shadow tests AS EXECUTED. `frac` above prices the step at the reference's work (the tests
+        # renderer.rs:46 would run, counted by a kernel that runs the reference's loops); the timed kernel skips tests behind
+        # remembered occluders and plane rows that cannot block a light. A second untimed pass runs the TIMED kernel's own
+        # code with counters on its tests and evaluations (HIPPT_FLAG_COUNT_EXECUTED): `frac_as_executed`.
+        fl_exec = cn_exec = None
+        if kernel == "megakernel":
+            with torch.cuda.stream(stream):
+                accum.zero_()
+                ctx.render_accum_device(accum.data_ptr(), s0, cnt, seed=0, max_depth=args.max_depth,
+                                        flags=args.flags | _abi.FLAG_COUNTERS | _abi.FLAG_COUNT_EXECUTED, stream=stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            if world == 1:
+                exec_sum = robust_sum(accum)
+                assert abs(step_sum - exec_sum) <= 2e-3 * abs(exec_sum), (step_sum, exec_sum)
+            cn_exec = ctx.read_counters()
+            ctx.kernel_time_ms()
+            fl_exec = flops.algorithmic_flops(cn_exec, len(scene.lights))
         out = {
             "metric": "Mpaths/s (node) at 1080p; % of FP32 VALU peak",
             "value": round(paths_step / (elapsed / args.steps) / 1e6, 2),
@@ -290,7 +338,7 @@ def main():
                      f"{scene_name} (the reference's example scene; no external data)"),
             "world_size": dist.get_world_size() if world > 1 else 1,
             "devices": devices,
-            "config": {"workload": f"{args.config.upper()}: {scene_name} {W}x{H}, {total_spp} spp image, "
+            "config": {"workload": f"{'128-spp chunk of C5' if args.config == 'c5' and spp_arg == 128 else args.config.upper()}: {scene_name} {W}x{H}, {total_spp} spp image, "
                                    f"{cnt} spp on rank 0, max_depth {args.max_depth}, seed 0",
                        "parallelism": (f"sample-range split over {world} GPUs ({args.scaling} scaling), one RCCL reduce"
                                        if world > 1 else "1 GPU"),
@@ -306,8 +354,18 @@ def main():
                          "kernel_ms": round(k_ms, 3), "launches_per_step": launches_per_step,
                          "note": "rank 0's GPU: algorithmic FLOPs (SURVEY §8d event costs x device event counters of this "
                                  "rank's share of a step) / mean trace-kernel duration from HIP events on the launch stream; "
-                                 "the path is VALU-bound (no MFMA)"},
+                                 "the path is VALU-bound (no MFMA). frac credits shadow tests as the REFERENCE executes them "
+                                 "(scene order up to the first occluder, renderer.rs:46); frac_as_executed credits the tests and "
+                                 "BRDF evaluations the timed kernel itself executes (SURVEY §8d's rule)"},
         }
+        if fl_exec is not None:
+            ach_exec = fl_exec / launches_per_step / (k_ms * 1e-3) / 1e12
+            out["roofline"]["frac_as_executed"] = round(ach_exec / FP32_VALU_PEAK_TFLOPS, 4)
+            out["roofline"]["achieved_as_executed"] = round(ach_exec, 3)
+            out["flop_per_path_as_executed"] = round(fl_exec / cn_exec["paths"], 1)
+            out["shadow_tests_per_path"] = {
+                "reference": round((cn["shadow_sphere_tests"] + cn["shadow_plane_tests"]) / cn["paths"], 2),
+                "executed": round((cn_exec["shadow_sphere_tests"] + cn_exec["shadow_plane_tests"]) / cn_exec["paths"], 2)}
         pmc_pending = pmc
         if lbvh and kernel == "wavefront+lbvh":
             # The LBVH queue pipeline is bound by what its rays FETCH, not by arithmetic (PMC: the traversal kernels wait on
@@ -364,6 +422,9 @@ def main():
                     r[k] = pmc_pending[k]
             if "note" in pmc_pending:
                 r["pmc_note"] = pmc_pending["note"]
+            # the PMC figures belong to the build they were measured on
+            r["pmc_csrc_hash"] = pmc_pending.get("csrc_hash")
+            r["pmc_stale"] = pmc_pending.get("csrc_hash") != csrc_hash()
             if r.get("bound") == "l2" and r.get("traffic"):  # north star: "for wavefront queues, achieved HBM GB/s is also reported"
                 r["hbm_gbs"] = round(r["traffic"] / (r["kernel_ms"] * r["launches_per_step"] * 1e-3) / 1e9, 1)
                 r["hbm_frac"] = round(r["hbm_gbs"] / 8000.0, 4)

@@ -126,6 +126,9 @@ typedef struct hippt_scene {
                                         listed more than once (several ranks share it: a one-GPU box can rehearse the
                                         split, the per-rank contexts / threads / streams and the sum) */
 
+#define HIPPT_FLAG_COUNT_EXECUTED 512u /* with HIPPT_FLAG_COUNTERS, table-scene megakernel: the timed kernel's own code runs
+                                        * and shadow_*_tests / lit_evals report the tests and evaluations IT executes
+                                        * (behind remembered occluders, without culled plane rows), not the reference's */
 #define HIPPT_FLAG_TRAVERSAL_STATS 256u /* LBVH queue pipeline: count what its rays fetch (hippt_read_traversal_stats) */
 
 typedef struct hippt_options {

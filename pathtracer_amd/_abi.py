@@ -19,6 +19,7 @@ FLAG_MEGAKERNEL = 32
 FLAG_NO_SLICES = 64
 FLAG_LOCAL_REDUCE = 128
 FLAG_TRAVERSAL_STATS = 256
+FLAG_COUNT_EXECUTED = 512
 
 COUNTER_NAMES = (
     "paths", "extend_rays", "extend_hits", "shadow_rays", "shadow_sphere_tests",

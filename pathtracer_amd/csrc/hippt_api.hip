@@ -496,7 +496,8 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
                     ctx->slice_bytes = need;
                 }
             }
-            HIP_TRY(pt::launch_megakernel(P, ctx->d_blob, d_accum, ctx->d_counters, count, lds, st, ctx->slice_buf, slices));
+            HIP_TRY(pt::launch_megakernel(P, ctx->d_blob, d_accum, ctx->d_counters, count, lds, st, ctx->slice_buf, slices,
+                                          (o.flags & HIPPT_FLAG_COUNT_EXECUTED) != 0));
         }
         HIP_TRY(hipEventRecord(ev.second, st));
         s0 += c;

@@ -394,7 +394,8 @@ template <class Tbl, int NS, bool COUNT, bool LEARN = false, bool CULL = false>
 __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, F3 x, float eps, const F3 (&l)[NS],
                                                const float (&tmax)[NS], bool (&occ)[NS], uint32_t &n_sph_tests,
                                                uint32_t &n_pl_tests, bool spheres = true, uint32_t *dominant = nullptr,
-                                               uint32_t *dominant_lanes = nullptr, uint32_t cull_row = 0u, bool active = true) {
+                                               uint32_t *dominant_lanes = nullptr, uint32_t cull_row = 0u, bool active = true,
+                                               uint32_t *plane_rows_run = nullptr) {
     const uint32_t n_sph = spheres ? P.n_sph : 0u;  // false: the caller has tested the spheres (BVH) and set occ[]
     if (spheres) {
 #pragma unroll
@@ -452,6 +453,7 @@ __device__ __forceinline__ void occluded_multi(const Tbl &tbl, const Params &P, 
         }
         bool hit[NS];
         plane_shadow_row<NS>(q0, q1, tbl.ld(o + 2), x, eps, l, q, hit);
+        if (plane_rows_run) ++*plane_rows_run;  // (executed-test counting build only)
         fold(hit, P.n_sph + j);
     }
     if (COUNT) {

@@ -11,7 +11,8 @@
 namespace pt {
 
 hipError_t launch_megakernel(const Params &P, const float4 *blob, float *accum, unsigned long long *counters,
-                             bool count, bool lds, hipStream_t st, float *partial = nullptr, uint32_t slices = 1);
+                             bool count, bool lds, hipStream_t st, float *partial = nullptr, uint32_t slices = 1,
+                             bool count_executed = false);
 hipError_t launch_megakernel_bvh(const Params &P, const float4 *blob, const Bvh &bvh, uint32_t stack_entries, float *accum,
                                  unsigned long long *counters, bool count, hipStream_t st);
 hipError_t launch_unit_intersect_global(const Params &P, const float4 *blob, uint32_t n, const float *ro, const float *rd,

@@ -45,12 +45,12 @@ static_assert(4 * sizeof(WaveAcc) + (size_t)BVH_STACK * 256 * 4 <= 64 * 1024, "L
 // only, and a finished path's radiance is added to its pixel's sum in LDS, so the image is the same as
 // with one lane per pixel up to the order of the f32 additions (which is fixed: the item order and the LDS
 // atomics of a wave are deterministic).
-template <class Tbl, bool COUNT, bool BVH = false, class WL = WaveLds>
+template <class Tbl, bool COUNT, bool BVH = false, class WL = WaveLds, bool EXEC = false>
 __device__ __forceinline__ void trace_pixel(const Params &P, Tbl tbl, uint32_t x_own, uint32_t y_own, bool in_image,
                                             float *__restrict__ accum, unsigned long long *__restrict__ counters,
                                             WL *wl, Bvh bvh = Bvh{}, uint32_t *stack = nullptr, bool overwrite = false) {
-    constexpr bool kSharedNee = PT_SHARED_NEE && !COUNT && !BVH;
-    Tracer<Tbl, COUNT, BVH> tr(P, tbl, bvh, stack);
+    constexpr bool kSharedNee = PT_SHARED_NEE && (!COUNT || EXEC) && !BVH;
+    Tracer<Tbl, COUNT, BVH, EXEC> tr(P, tbl, bvh, stack);
 #ifdef PT_NEE_DIAG
     tr.diag = counters;
 #endif
@@ -251,7 +251,7 @@ __device__ __forceinline__ float *sample_slice(Params &P, float *accum) {
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 5  // waves per SIMD the register allocator must allow (launch_bounds 2nd argument)
 #endif
-template <bool COUNT>
+template <bool COUNT, bool EXEC = false>
 __global__ __launch_bounds__(256, PT_MIN_WAVES) void pt_megakernel_lds(Params P, const float4 *__restrict__ blob,
                                                          float *__restrict__ accum,
                                                          unsigned long long *__restrict__ counters) {
@@ -263,11 +263,11 @@ __global__ __launch_bounds__(256, PT_MIN_WAVES) void pt_megakernel_lds(Params P,
     bool in_image = (x < P.width) & (y < P.height);
     __shared__ WaveLds s_wl[4];
     float *out = sample_slice(P, accum);
-    trace_pixel<TblLds, COUNT>(P, TblLds{s_tbl}, x, y, in_image, out, counters, &s_wl[threadIdx.x >> 6], Bvh{}, nullptr, gridDim.y > 1u);
+    trace_pixel<TblLds, COUNT, false, WaveLds, EXEC>(P, TblLds{s_tbl}, x, y, in_image, out, counters, &s_wl[threadIdx.x >> 6], Bvh{}, nullptr, gridDim.y > 1u);
 }
 
 // Scene tables read from global memory (scenes too large for LDS).
-template <bool COUNT>
+template <bool COUNT, bool EXEC = false>
 __global__ __launch_bounds__(256) void pt_megakernel_global(Params P, const float4 *__restrict__ blob,
                                                             float *__restrict__ accum,
                                                             unsigned long long *__restrict__ counters) {
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void pt_megakernel_global(Params P, const floa
     bool in_image = (x < P.width) & (y < P.height);
     __shared__ WaveLds s_wl[4];
     float *out = sample_slice(P, accum);
-    trace_pixel<TblGlobal, COUNT>(P, TblGlobal{blob}, x, y, in_image, out, counters, &s_wl[threadIdx.x >> 6], Bvh{}, nullptr, gridDim.y > 1u);
+    trace_pixel<TblGlobal, COUNT, false, WaveLds, EXEC>(P, TblGlobal{blob}, x, y, in_image, out, counters, &s_wl[threadIdx.x >> 6], Bvh{}, nullptr, gridDim.y > 1u);
 }
 
 // Many-sphere scenes: spheres through the LBVH, everything else from global tables.
@@ -508,13 +508,18 @@ __global__ __launch_bounds__(256) void pt_add_partials(float *__restrict__ accum
 // slices > 1: the sample range is cut into `slices` parts rendered by separate blocks into `partial`
 // (slices x width*height*3 floats), which are then added to accum in a fixed order.
 hipError_t launch_megakernel(const Params &P, const float4 *blob, float *accum, unsigned long long *counters,
-                             bool count, bool lds, hipStream_t st, float *partial, uint32_t slices) {
+                             bool count, bool lds, hipStream_t st, float *partial, uint32_t slices, bool count_executed) {
     uint32_t tiles_y = (P.height + 15u) / 16u;
     if (slices < 1u || !partial) slices = 1u;
     dim3 grid(P.tiles_x * tiles_y, slices), block(256);
     float *out = slices > 1u ? partial : accum;
     size_t shmem = (size_t)P.blob_f4 * sizeof(float4);
-    if (lds) {
+    if (count && count_executed) {  // the TIMED kernels' own code (wave-shared lights loop), counting the tests it executes
+        if (lds)
+            hipLaunchKernelGGL((pt_megakernel_lds<true, true>), grid, block, shmem, st, P, blob, out, counters);
+        else
+            hipLaunchKernelGGL((pt_megakernel_global<true, true>), grid, block, 0, st, P, blob, out, counters);
+    } else if (lds) {
         if (count)
             hipLaunchKernelGGL(pt_megakernel_lds<true>, grid, block, shmem, st, P, blob, out, counters);
         else

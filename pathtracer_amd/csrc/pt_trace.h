@@ -38,7 +38,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // BVH = true: spheres through the LBVH (pt_bvh.h), planes through the table loops.
-template <class Tbl, bool COUNT, bool BVH>
+// EXEC (with COUNT): the counters of the shadow tests and BRDF evaluations report what THIS code executes — the
+// wave-shared lights loop with its remembered occluders, culled plane rows and deferred evaluations — instead of what
+// the reference's loop would (SURVEY §8d credits shadow tests "as executed"; bench.py prints both fractions).
+template <class Tbl, bool COUNT, bool BVH, bool EXEC = false>
 struct Tracer {
     const Params &P;
     Tbl tbl;
@@ -161,6 +164,8 @@ struct Tracer {
             float pt[1] = {pr[6 * kPairCap]};
             bool po[1];
             occluded_multi<Tbl, 1, false>(tbl, P, px, 1e-4f, pl, pt, po, d0, d1);
+            bump(HIPPT_C_SHADOW_SPHERE_TESTS, P.n_sph);
+            bump(HIPPT_C_SHADOW_PLANE_TESTS, P.n_pl);
             if (!po[0]) {
                 // the ray arrives: renderer.rs:49-77 for it, here rather than in the lane that drew it — on the list
                 // the wave's few survivors of a mostly blocked light sit side by side
@@ -172,6 +177,7 @@ struct Tracer {
                 const float4 l0 = tbl.ld(o), l3 = tbl.ld(o + 3), l4 = tbl.ld(o + 4);
                 bool lit;
                 F3 c = nee_eval(sk, pl[0], pr[7 * kPairCap], f3(l4), l0.w, f3(l3), lit);
+                if (lit) bump(HIPPT_C_LIT_EVALS);
                 c = F3{pr[14 * kPairCap], pr[15 * kPairCap], pr[16 * kPairCap]} * c * 0.25f;  // :82, and the path throughput (:285 / :325)
                 float *a = acc + ((w >> 23) & 63u) * 3u;
                 __hip_atomic_fetch_add(a + 0, c.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -189,10 +195,14 @@ struct Tracer {
     }
     __device__ __forceinline__ void direct_light_shared(bool nee, F3 x, F3 n, F3 v, uint32_t mat_id, Rng &rng, F3 T,
                                                         F3 &psum, uint32_t pix, NeeShare *sh, float *acc) {
-        static_assert(!COUNT && !BVH, "the counting and LBVH kernels use direct_light");
+        static_assert((!COUNT || EXEC) && !BVH, "the reference-counting and LBVH kernels use direct_light");
         static_assert(kHintLights <= 8, "the list word keeps the light in 3 bits");
         const uint32_t n_nee = (uint32_t)__popcll(ballot64(nee));
         if (n_nee == 0u) return;
+        if (nee) {
+            bump(HIPPT_C_NEE_VERTICES);
+            bump(HIPPT_C_SHADOW_RAYS, 4u * P.n_light);
+        }
         // not kept in a register across trips: a lane whose pool item lies outside the image skips the trip
         uint32_t pending = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&sh->pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         uint32_t dummy0 = 0, dummy1 = 0;
@@ -231,6 +241,7 @@ struct Tracer {
                 if (nee) {
                     bool hit[4];
                     object_shadow<Tbl, 4>(tbl, P, h, x, 1e-4f, l, tmax, hit);
+                    bump(h < P.n_sph ? HIPPT_C_SHADOW_SPHERE_TESTS : HIPPT_C_SHADOW_PLANE_TESTS, 4u);
 #pragma unroll
                     for (int s = 0; s < 4; ++s)  // a sample that faces away contributes nothing (:50,:55)
                         if (!hit[s] & (dot(n, l[s]) > 0.0f) & (-dot(l[s], f3(l4)) > 0.0f)) surv |= 1u << s;
@@ -282,8 +293,11 @@ struct Tracer {
             if (full && nee) {
                 bool occ[4];
                 uint32_t dom, dom_lanes;
+                uint32_t rows_run = 0u;
                 occluded_multi<Tbl, 4, false, true, PT_CULL != 0>(tbl, P, x, 1e-4f, l, tmax, occ, dummy0, dummy1, true, &dom, &dom_lanes,
-                                                          P.cull_off + li * P.cull_stride);
+                                                          P.cull_off + li * P.cull_stride, true, COUNT ? &rows_run : nullptr);
+                bump(HIPPT_C_SHADOW_SPHERE_TESTS, 4u * P.n_sph);
+                bump(HIPPT_C_SHADOW_PLANE_TESTS, 4u * rows_run);
                 // worth remembering if the lanes it leaves over fit a batch: at most 4 rays each
                 if (li < kHintLights && dom_lanes != 0u && (n_nee - dom_lanes) * 4u <= PT_HINT_SLACK)
                     __hip_atomic_store(&sh->hint[li], dom, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -310,6 +324,7 @@ struct Tracer {
                     if (surv & (1u << s)) {
                         bool lit;
                         contrib = contrib + nee_eval(sk, l[s], id2[s], f3(l4), l0.w, f3(l3), lit);
+                        if (lit) bump(HIPPT_C_LIT_EVALS);
                     }
                 }
                 psum = madd(psum, T * contrib, 0.25f);  // :82 and :285 / :325, straight into the path's sum

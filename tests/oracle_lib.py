@@ -28,9 +28,19 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def build_fast_oracle(out_dir):
+    """The CPU-baseline build of the same source (bench.py, SURVEY §8d: -O3 -march=native), compiled ON the machine that
+    times it — a -march=native library built elsewhere may not run here — into out_dir. Returns (path, flags)."""
+    flags = "-O3 -march=native -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -pthread"
+    out = os.path.join(out_dir, "liboracle_fast.so")
+    subprocess.check_call(["g++"] + flags.split() + ["-shared", "-o", out, os.path.join(ORACLE_DIR, "pt_oracle.cpp")],
+                          stdout=subprocess.DEVNULL)
+    return out, flags
+
+
 class Oracle:
-    def __init__(self):
-        self.lib = C.CDLL(build_oracle())
+    def __init__(self, path=None):
+        self.lib = C.CDLL(path or build_oracle())
         self.lib.orc_last_error.restype = C.c_char_p
         self.lib.orc_autofocus.restype = C.c_float
         self.unit = UnitOps(self.lib, "orc_test_", 0, self.lib.orc_last_error)
