@@ -48,6 +48,11 @@ namespace {
 // Paths per launch: bounds one launch to a fraction of a second so that long
 // renders stay observable (analogue of the 600 M budget, gpu_renderer.rs:94).
 constexpr uint64_t kPathsPerLaunch = 4ull << 30;
+// Samples per pixel and launch: a launch keeps a pixel's running sum of a slice (an eighth of its samples) in f32, and
+// a running f32 sum of n terms loses ~6e-8 sqrt(n) of its value. 4 096 samples per launch = 512 per slice keep that at
+// ~1e-6 for any sample count (the showcase job has 131 072, README.md:265-268; SURVEY §7.3 "hierarchical accumulation");
+// the launches' sums are then added to the accumulator one by one.
+constexpr uint64_t kSamplesPerLaunch = 4096;
 // LDS budget for the staged tables: a block may use 64 KiB without opting in to more, and the megakernel
 // keeps 4 x WaveLds (pixel sums, pending shadow rays) of static LDS beside the tables.
 const size_t kMaxLdsBlob = 64 * 1024 - pt::megakernel_static_lds();
@@ -414,7 +419,7 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
                                                       "<= 65535 materials, max_depth <= 31 and (LBVH scenes) <= 96 lights, < 2^24 spheres + nodes, "
                                                       "pixels x 4 x lights < 2^32");
         // LBVH pipeline: several sample streams per pixel (pt_wavefront_bvh.hip), sized for the largest chunk of this call
-        const uint64_t per_chunk = std::max<uint64_t>(1, kPathsPerLaunch / pixels);
+        const uint64_t per_chunk = std::max<uint64_t>(1, std::min(kPathsPerLaunch / pixels, kSamplesPerLaunch));
         if (use_bvh && !(o.flags & HIPPT_FLAG_NO_SLICES))
             P.wf_streams_log2 = pt::wfb_streams_log2((uint32_t)pixels, (uint32_t)std::min<uint64_t>(cnt, per_chunk), P.n_light);
         size_t need = use_bvh ? pt::wfb_workspace_bytes((uint32_t)pixels << P.wf_streams_log2, P.n_light) : pt::wf_workspace_bytes((uint32_t)pixels);
@@ -452,7 +457,7 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
             ctx->slice_bytes = need_slices;
         }
     }
-    uint64_t per = kPathsPerLaunch / pixels;
+    uint64_t per = std::min(kPathsPerLaunch / pixels, kSamplesPerLaunch);
     if (per < 1) per = 1;
     while (cnt > 0) {
         uint32_t c = (uint32_t)std::min<uint64_t>(cnt, per);
@@ -539,7 +544,7 @@ int hippt_render_accum_device_noalloc(hippt_context *ctx, const hippt_options *o
     const bool count = (o.flags & HIPPT_FLAG_COUNTERS) != 0;
     bool lds = (size_t)P.blob_f4 * sizeof(float4) <= kMaxLdsBlob;
     if (o.flags & HIPPT_FLAG_TABLES_GLOBAL) lds = false;
-    uint64_t per = kPathsPerLaunch / pixels;
+    uint64_t per = std::min(kPathsPerLaunch / pixels, kSamplesPerLaunch);
     if (per < 1) per = 1;
     while (cnt > 0) {
         const uint32_t c = (uint32_t)std::min<uint64_t>(cnt, per);

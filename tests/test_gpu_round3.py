@@ -47,3 +47,35 @@ def test_light_side_table_is_bounded_and_optional(oracle):
     ctx = hip_renderer.Context(0)
     ctx.set_scene(big)
     ctx.close()
+
+
+def test_showcase_sample_count_in_one_accumulator(oracle):
+    """VERDICT r02 missing #3: the showcase job's SAMPLE COUNT (131 072 per pixel, README.md:265-268). One call sums
+    all of them into one f32 accumulator (launches of at most 4 096 samples, slices inside a launch): it must equal the
+    float64 sum of 128 separate 1 024-sample renders to 1e-5 per pixel, and agree in the mean with the oracle."""
+    import torch
+    from pathtracer_amd import Scene, hip_renderer
+    W, H, SPP = 64, 48, 131072
+    s = Scene.load(os.path.join(ROOT, "scenes", "scene.example.json"), W, H, SPP)
+    one = hip_renderer.render_accum(s, 0, SPP, seed=4).astype(np.float64)
+    ctx = hip_renderer.Context(0)
+    ctx.set_scene(s)
+    dev = torch.device("cuda", 0)
+    buf = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+    total = np.zeros(H * W * 3, np.float64)
+    for k in range(128):
+        buf.zero_()
+        torch.cuda.synchronize(dev)
+        ctx.render_accum_device(buf.data_ptr(), k * 1024, 1024, seed=4)
+        ctx.kernel_time_ms()  # synchronises
+        total += buf.cpu().numpy().astype(np.float64)
+    total = total.reshape(H, W, 3)
+    rel = np.abs(one - total) / np.maximum(total, 1e-3 * SPP)
+    assert rel.max() <= 1e-5, rel.max()
+    # against the CPU restatement at 4 096 spp (other samples of the same streams: a statistical comparison)
+    o = oracle.render_accum(Scene.load(os.path.join(ROOT, "scenes", "scene.example.json"), W, H, 4096), seed=4).astype(np.float64)
+    m_gpu, m_cpu = total.mean() / SPP, o.mean() / 4096
+    assert abs(m_gpu - m_cpu) <= 1e-2 * m_cpu, (m_gpu, m_cpu)
+    # and the first 4 096 samples of the same streams agree sample for sample
+    first = hip_renderer.render_accum(s, 0, 4096, seed=4).astype(np.float64)
+    assert abs(first.sum() - o.sum()) <= 2e-3 * o.sum()
