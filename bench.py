@@ -128,6 +128,9 @@ def parse_args(argv=None):
     ap.add_argument("--max-depth", type=int, default=5)
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 rehearsal on a box with ONE GPU: every rank renders on device 0 and the accumulators are "
+                         "summed through gloo on the host instead of RCCL (same split, timing and JSON code; not a measurement)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: gloo ranks exchange their sample counts instead of rendering (launcher / split / reduce check)")
     return ap.parse_args(argv)
@@ -210,12 +213,17 @@ def main():
     from pathtracer_amd import Scene, _abi, flops, hip_renderer
     from pathtracer_amd.partition import sample_range
 
-    if world > 1:
+    rehearse = args.rehearse_on_one_gpu and world > 1
+    if rehearse:
+        local_rank = 0
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearse else dev  # where the small bookkeeping collectives run
 
     cW, cH, cS, cscene = CONFIGS[args.config]
     W, H = args.width or cW, args.height or cH
@@ -236,13 +244,27 @@ def main():
     stream = torch.cuda.Stream(dev)  # a real (non-NULL) stream: NULL would mean "the context's own stream" to the C ABI
     assert stream.cuda_stream != 0
 
-    def step(flags=args.flags):
+    reduce_events = []  # (start, end) around the RCCL reduce of each timed step, on the launch stream
+
+    def step(flags=args.flags, timed=False):
         with torch.cuda.stream(stream):
             accum.zero_()
             ctx.render_accum_device(accum.data_ptr(), s0, cnt, seed=0, max_depth=args.max_depth, flags=flags,
                                     stream=stream.cuda_stream)
             if world > 1:
-                dist.reduce(accum, dst=0)  # RCCL sum of the per-GPU accumulators, queued behind the kernels
+                if timed:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record(stream)
+                if rehearse:  # one-GPU rehearsal: the sum goes through the host
+                    stream.synchronize()
+                    host = accum.cpu()
+                    dist.reduce(host, dst=0)
+                    accum.copy_(host)
+                else:
+                    dist.reduce(accum, dst=0)  # RCCL sum of the per-GPU accumulators, queued behind the kernels
+                if timed:
+                    ev[1].record(stream)
+                    reduce_events.append(ev)
             if rank == 0:
                 ctx.resolve_device(accum.data_ptr(), total_spp, rgba.data_ptr(), stream=stream.cuda_stream)
 
@@ -257,18 +279,33 @@ def main():
     ctx.kernel_time_ms()  # drop warmup launches from the kernel timing
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(timed=True)
     sync()
     elapsed = time.perf_counter() - t0
     devices = [local_rank]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(ids, torch.tensor([local_rank], dtype=torch.int64, device=dev))
+        ids = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([local_rank], dtype=torch.int64, device=cdev))
         devices = [int(x.item()) for x in ids]
     kernel_ms, launches = ctx.kernel_time_ms()
+    per_rank = None
+    if world > 1:
+        # what a scaling curve needs to be read: the trace kernels' time per step on the slowest and the fastest rank,
+        # and the time the launch stream spends in the reduce (which includes waiting for the slowest rank's kernels)
+        k_step = kernel_ms / max(args.steps, 1)
+        red = sum(a.elapsed_time(b) for a, b in reduce_events) / max(len(reduce_events), 1)
+        tmax = torch.tensor([k_step, red], dtype=torch.float64, device=cdev)
+        tmin = tmax.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        per_rank = {"kernel_ms_max": round(float(tmax[0]), 3), "kernel_ms_min": round(float(tmin[0]), 3),
+                    "reduce_ms": round(float(tmax[1]), 3), "reduce_ms_min": round(float(tmin[1]), 3),
+                    "note": "per step: trace-kernel time (HIP events on the launch stream) of the slowest / fastest rank; reduce_ms = "
+                            "launch-stream time inside torch.distributed.reduce (RCCL), max / min over ranks — a rank that "
+                            "finishes its kernels early waits there for the others"}
 
     out = None
     if rank == 0:
@@ -428,6 +465,10 @@ def main():
             if r.get("bound") == "l2" and r.get("traffic"):  # north star: "for wavefront queues, achieved HBM GB/s is also reported"
                 r["hbm_gbs"] = round(r["traffic"] / (r["kernel_ms"] * r["launches_per_step"] * 1e-3) / 1e9, 1)
                 r["hbm_frac"] = round(r["hbm_gbs"] / 8000.0, 4)
+        if per_rank:
+            out["per_rank"] = per_rank
+        if rehearse:
+            out["rehearsal"] = "every rank on device 0, host-side gloo sum: NOT a measurement of N GPUs"
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: the other ranks would wait at the barrier
             out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
     if world > 1:

@@ -79,3 +79,23 @@ def test_showcase_sample_count_in_one_accumulator(oracle):
     # and the first 4 096 samples of the same streams agree sample for sample
     first = hip_renderer.render_accum(s, 0, 4096, seed=4).astype(np.float64)
     assert abs(first.sum() - o.sum()) <= 2e-3 * o.sum()
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """bench.py's N > 1 code (rank launcher, sample split, reduce, per-rank timing, JSON) with the real kernels on the
+    one GPU of this box: both ranks render on device 0 and the sum goes through gloo. With two GPUs visible
+    tests/test_gpu_two_devices.py runs the same through RCCL."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--spp", "64", "--width", "640", "--height", "360", "--rehearse-on-one-gpu"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["scaling"] == "strong" and "rehearsal" in d
+    assert d["per_rank"]["kernel_ms_max"] >= d["per_rank"]["kernel_ms_min"] > 0 and d["per_rank"]["reduce_ms"] > 0
+    assert d["config"]["workload"].count("32 spp on rank 0") == 1
