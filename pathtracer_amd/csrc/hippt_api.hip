@@ -273,6 +273,7 @@ struct hippt_context {
     uint32_t samples = 0;
     void *wf_ws = nullptr;  // wavefront path-state workspace (allocated on first use)
     size_t wf_ws_bytes = 0;
+    uint32_t wf_streams_cap = 31;  // log2 of the sample streams per pixel the queue allocations of this context have been found to allow
     pt::BvhBuffers bvh;  // LBVH over the spheres (many-sphere scenes only)
     int bvh_depth = 0;
     std::string bvh_error;  // why the last hippt_set_scene could not build the LBVH (the scene then renders only with HIPPT_FLAG_NO_BVH)
@@ -422,39 +423,45 @@ int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts, flo
         const uint64_t per_chunk = std::max<uint64_t>(1, std::min(kPathsPerLaunch / pixels, kSamplesPerLaunch));
         if (use_bvh && !(o.flags & HIPPT_FLAG_NO_SLICES))
             P.wf_streams_log2 = pt::wfb_streams_log2((uint32_t)pixels, (uint32_t)std::min<uint64_t>(cnt, per_chunk), P.n_light);
-        size_t need = use_bvh ? pt::wfb_workspace_bytes((uint32_t)pixels << P.wf_streams_log2, P.n_light) : pt::wf_workspace_bytes((uint32_t)pixels);
-        if (need > ctx->wf_ws_bytes) {
-            HIP_TRY(hipStreamSynchronize(st));
-            if (ctx->wf_ws) HIP_TRY(hipFree(ctx->wf_ws));
-            ctx->wf_ws = nullptr;
-            ctx->wf_ws_bytes = 0;
-            // The LBVH queues are sized for throughput (up to 64 GiB of an otherwise empty 288 GB GPU). On a GPU that
-            // cannot spare that much, halve the number of sample streams until the queues fit: slower, same image.
-            hipError_t me = hipMalloc(&ctx->wf_ws, need);
-            while (me == hipErrorOutOfMemory && use_bvh && P.wf_streams_log2 > 0) {
-                (void)hipGetLastError();
-                --P.wf_streams_log2;
-                need = pt::wfb_workspace_bytes((uint32_t)pixels << P.wf_streams_log2, P.n_light);
+        if (use_bvh) P.wf_streams_log2 = std::min(P.wf_streams_log2, ctx->wf_streams_cap);  // what an earlier call found to fit
+        // The LBVH queues are sized for throughput (tens of GiB of an otherwise empty 288 GB GPU), and the streams' partial
+        // sums grow with them. On a GPU that cannot spare that much, halve the number of sample streams until BOTH fit:
+        // slower, same image. The stream count that fitted is remembered, so later calls do not repeat the failing
+        // allocations.
+        for (;;) {
+            const size_t need = use_bvh ? pt::wfb_workspace_bytes((uint32_t)pixels << P.wf_streams_log2, P.n_light) : pt::wf_workspace_bytes((uint32_t)pixels);
+            const size_t need_slices = use_bvh ? ((size_t)pixels * 3 * sizeof(float)) << P.wf_streams_log2 : 0;  // the streams' running sums
+            hipError_t me = hipSuccess;
+            if (need > ctx->wf_ws_bytes) {
+                HIP_TRY(hipStreamSynchronize(st));
+                if (ctx->wf_ws) HIP_TRY(hipFree(ctx->wf_ws));
+                ctx->wf_ws = nullptr;
+                ctx->wf_ws_bytes = 0;
                 me = hipMalloc(&ctx->wf_ws, need);
+                if (me == hipSuccess) {
+                    ctx->wf_ws_bytes = need;
+                    if (std::getenv("HIPPT_DEBUG"))
+                        std::fprintf(stderr, "[hippt] queue workspace %.2f GiB, %u sample streams per pixel\n", (double)need / (1ull << 30), 1u << P.wf_streams_log2);
+                }
             }
-            HIP_TRY(me);
-            ctx->wf_ws_bytes = need;
-            if (std::getenv("HIPPT_DEBUG"))
-                std::fprintf(stderr, "[hippt] queue workspace %.2f GiB, %u sample streams per pixel\n", (double)need / (1ull << 30), 1u << P.wf_streams_log2);
+            if (me == hipSuccess && need_slices > ctx->slice_bytes) {
+                HIP_TRY(hipStreamSynchronize(st));
+                if (ctx->slice_buf) HIP_TRY(hipFree(ctx->slice_buf));
+                ctx->slice_buf = nullptr;
+                ctx->slice_bytes = 0;
+                me = hipMalloc((void **)&ctx->slice_buf, need_slices);
+                if (me == hipSuccess) ctx->slice_bytes = need_slices;
+            }
+            if (me == hipSuccess) break;
+            if (me != hipErrorOutOfMemory || !use_bvh || P.wf_streams_log2 == 0) HIP_TRY(me);
+            (void)hipGetLastError();
+            --P.wf_streams_log2;
+            ctx->wf_streams_cap = P.wf_streams_log2;
         }
         if (use_bvh && !ctx->stream2) {
             HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-        }
-        const size_t need_slices = use_bvh ? ((size_t)pixels * 3 * sizeof(float)) << P.wf_streams_log2 : 0;  // the streams' running sums
-        if (need_slices > ctx->slice_bytes) {
-            HIP_TRY(hipStreamSynchronize(st));
-            if (ctx->slice_buf) HIP_TRY(hipFree(ctx->slice_buf));
-            ctx->slice_buf = nullptr;
-            ctx->slice_bytes = 0;
-            HIP_TRY(hipMalloc((void **)&ctx->slice_buf, need_slices));
-            ctx->slice_bytes = need_slices;
         }
     }
     uint64_t per = std::min(kPathsPerLaunch / pixels, kSamplesPerLaunch);

@@ -894,6 +894,15 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
 
     const unsigned blocks_all = (n + 255) / 256;
     const unsigned grid = wfb_queue_blocks(n);
+    // the shading kernel needs 98 VGPRs (5 blocks per CU): launched with the 8 blocks per CU of `grid`, three eighths of
+    // its blocks would start only when the first ones end; its grid is what is resident at once
+    unsigned grid_shade = grid;
+    {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)wfb_shade, 256, 0) == hipSuccess && per_cu > 0 &&
+            hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            grid_shade = std::min(grid, (unsigned)(per_cu * cus));
+    }
     if (wfb_ray_positions(n, P.n_light) >= kMaxRayIds) return hipErrorInvalidValue;
     const unsigned grid_trav = kGridTrav;
     if (stack_entries > kWideStackCap || !bvh.wide || (uint64_t)bvh.n + bvh.n_wide > (1ull << 24)) return hipErrorInvalidValue;  // wfb_supports()
@@ -958,7 +967,7 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
                 hipLaunchKernelGGL((WFB_TRAV<true, false>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[2], blob,
                                    (const uint32_t *)(counters + 256), &counters[4], (int *)nullptr, A.occ, (const uint32_t *)A.ids, (const uint32_t *)&counters[5],
                                    (unsigned long long *)nullptr, lds_entries, A.spill, idx_bits, n_top, P.light_off, P.n_light);
-            hipLaunchKernelGGL(wfb_shade, dim3(grid), dim3(256), 0, s, P, blob, A.Q[2], (const uint32_t *)A.occ,
+            hipLaunchKernelGGL(wfb_shade, dim3(grid_shade), dim3(256), 0, s, P, blob, A.Q[2], (const uint32_t *)A.occ,
                                A.Q[1 - cur], sums);
         }
         cur = 1 - cur;
