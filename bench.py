@@ -441,7 +441,10 @@ def main():
                                 "leaf_fetches": round(ts[k]["leaf_fetches"] / max(ts[k]["rays"], 1), 1),
                                 "bytes": round(((ts[k]["nodes"] - ts[k]["nodes_from_lds"]) * node_b + ts[k]["leaf_fetches"] * leaf_b + ts[k]["aux_rows"] * 16) / max(ts[k]["rays"], 1))}
                             for k in ("closest", "any")},
-                "valu_fp32": {"achieved_tflops": round(achieved, 3), "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4)},
+                "valu_fp32": {"achieved_tflops": round(achieved, 3), "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
+                              "note": "sphere / plane tests and shading only: the cost table of SURVEY §8d prices no box tests"},
+                "limiter": "valu_issue (PMC: the traversal kernels keep every SIMD's vector ALU busy at 61-66 % active lanes, "
+                           "DESIGN.md §3; the byte roofline says how far the fetch path is from the L2's rate, not what limits the step)",
                 "note": "rank 0's GPU: algorithmic bytes of a step (64 B per 4-wide BVH node visited outside the LDS-resident first levels, "
                         "16 B per sphere fetched, 16 B per aux row, ray records, queue entries read and written by the logic / shading kernels) "
                         "/ duration of the step's kernels from HIP events on the launch stream, against the aggregate L2 rate of "
@@ -454,7 +457,7 @@ def main():
             r = out["roofline"]
             r["traffic"] = pmc_pending.get("traffic_bytes")
             r["traffic_source"] = f"{pmc_pending.get('source')} (rocprofv3 --pmc pass of this command on an earlier run; not measured in this run)"
-            for k in ("hw_flop_frac", "lanes_active", "l2_hit_rate", "l1_hit_rate"):
+            for k in ("hw_flop_frac", "lanes_active", "l2_hit_rate", "l1_hit_rate", "valu_busy"):
                 if k in pmc_pending:
                     r[k] = pmc_pending[k]
             if "note" in pmc_pending:
