@@ -30,6 +30,7 @@ pub struct hippt_options { pub sample_begin: u32, pub sample_count: u32, pub max
 
 // hippt_options.flags (include/hippt.h)
 pub const HIPPT_FLAG_LOCAL_REDUCE: u32 = 128;     // *_multi: a device may appear several times, device add instead of ncclReduce
+pub const HIPPT_FLAG_COUNT_EXECUTED: u32 = 512;  // with COUNTERS: shadow tests / evaluations as the timed kernel executes them
 pub const HIPPT_FLAG_TRAVERSAL_STATS: u32 = 256;  // LBVH pipeline: count node / leaf fetches (hippt_read_traversal_stats)
 
 extern "C" {
