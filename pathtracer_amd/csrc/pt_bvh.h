@@ -124,9 +124,11 @@ __device__ __forceinline__ bool slot_hit(const BoxRay &b, uint4 q, float t_max, 
     auto hi16 = [](uint32_t v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16)); };
     const F3 c = F3{lo16(q.x), hi16(q.x), lo16(q.y)}, h = F3{hi16(q.y), lo16(q.z), hi16(q.z)};
     const float cx = fmaf(c.x, b.slope.x, b.off.x), cy = fmaf(c.y, b.slope.y, b.off.y), cz = fmaf(c.z, b.slope.z, b.off.z);
-    const float nx = fmaf(-h.x, b.aslope.x, cx), fx = fmaf(h.x, b.aslope.x, cx);
-    const float ny = fmaf(-h.y, b.aslope.y, cy), fy = fmaf(h.y, b.aslope.y, cy);
-    const float nz = fmaf(-h.z, b.aslope.z, cz), fz = fmaf(h.z, b.aslope.z, cz);
+    // |slope| as a source modifier of the instruction rather than three more registers of per-ray state
+    const float ax = fabsf(b.slope.x), ay = fabsf(b.slope.y), az = fabsf(b.slope.z);
+    const float nx = fmaf(-h.x, ax, cx), fx = fmaf(h.x, ax, cx);
+    const float ny = fmaf(-h.y, ay, cy), fy = fmaf(h.y, ay, cy);
+    const float nz = fmaf(-h.z, az, cz), fz = fmaf(h.z, az, cz);
     t_entry = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
     return t_entry <= fminf(fminf(fx, fy), fminf(fz, t_max));
 }

@@ -49,6 +49,26 @@ def test_bvh_matches_brute_force_exactly(hip, oracle, scene20k):
     assert np.median(e) < 1e-6 and np.quantile(e, 0.95) < 1e-4 and e.max() < 1e-3
 
 
+def test_ploc_builder_gives_the_same_hits_and_the_same_image(hip, scene20k, monkeypatch):
+    """The opt-in PLOC tree (HIPPT_BVH_BUILDER=ploc, pt_bvh_build.hip) only changes which boxes are visited: closest
+    hits equal the brute-force loop's, and the queue pipeline's image equals the radix tree's bit for bit."""
+    from pathtracer_amd import _abi, hip_renderer
+    rng = np.random.default_rng(11)
+    n = 1 << 14
+    ro, rd = _camera_rays(hip, scene20k, n, rng)
+    ro2 = np.stack([rng.uniform(-40, 40, n), rng.uniform(0.1, 12, n), rng.uniform(4, 84, n)], 1).astype(np.float32)
+    ro, rd = np.concatenate([ro, ro2]), np.concatenate([rd, unit_vectors(rng, n)])
+    t_b, n_b, i_b = hip.intersect(scene20k, ro, rd)
+    s = scene20k.with_render(128, 72, 5)
+    img_radix = hip_renderer.render_accum(s, seed=9, flags=_abi.FLAG_WAVEFRONT)
+    for radius in ("2", "8", "40"):
+        monkeypatch.setenv("HIPPT_BVH_BUILDER", "ploc")
+        monkeypatch.setenv("HIPPT_BVH_PLOC_RADIUS", radius)
+        t_v, n_v, i_v = hip.intersect_bvh(scene20k, ro, rd)
+        assert np.array_equal(i_b, i_v) and np.array_equal(t_b, t_v) and np.array_equal(n_b, n_v), radius
+        assert np.array_equal(hip_renderer.render_accum(s, seed=9, flags=_abi.FLAG_WAVEFRONT), img_radix), radius
+
+
 def test_bvh_tie_rule_and_duplicates(hip):
     """Coincident spheres (identical centre and radius, many of them, so identical Morton codes):
     the lowest scene order must win, as Iterator::min_by keeps the first minimum."""

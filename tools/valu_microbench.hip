@@ -38,6 +38,14 @@ __global__ __launch_bounds__(256) void k(float *out, float a, float b, unsigned 
             asm volatile("v_perm_b32 %0, %9, %0, %8\n v_perm_b32 %1, %9, %1, %8\n v_perm_b32 %2, %9, %2, %8\n v_perm_b32 %3, %9, %3, %8\n v_perm_b32 %4, %9, %4, %8\n v_perm_b32 %5, %9, %5, %8\n v_perm_b32 %6, %9, %6, %8\n v_perm_b32 %7, %9, %7, %8\n"
                          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "s"(a), "v"(b), "v"(x0b));
         }
+        if (MODE == 46) {  // v_fma_mix_f32, first source a half (low word) -- the wide-node box decode
+            asm volatile("v_fma_mix_f32 %0, %10, %8, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %10, %8, %1 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %10, %8, %2 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %10, %8, %3 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %4, %10, %8, %4 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %10, %8, %5 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %6, %10, %8, %6 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %10, %8, %7 op_sel_hi:[1,0,0]\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b), "v"(x0b));
+        }
+        if (MODE == 47) {  // the same, high word, negated
+            asm volatile("v_fma_mix_f32 %0, -%10, %8, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, -%10, %8, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, -%10, %8, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, -%10, %8, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %4, -%10, %8, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, -%10, %8, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %6, -%10, %8, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, -%10, %8, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b), "v"(x0b));
+        }
         if (MODE == 0) {  // 8 independent fma chains
             asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
                          "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
@@ -222,6 +230,8 @@ int main() {
     run<42>("v_cvt_f32_u32_sdwa WORD_1", d, dc);
     run<43>("v_cvt_f32_ubyte1", d, dc);
     run<44>("v_cvt_f32_f16", d, dc);
+    run<46>("v_fma_mix_f32 (half src0, lo)", d, dc);
+    run<47>("v_fma_mix_f32 (-half src0, hi)", d, dc);
     run<0>("fma independent", d, dc);
     run<24>("v_cvt_f32_u32", d, dc);
     return 0;
