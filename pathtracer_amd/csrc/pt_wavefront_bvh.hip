@@ -825,7 +825,18 @@ namespace {
 struct WfbLayout {
     size_t per_queue, hits, occ, ids, total;
 };
-constexpr unsigned kGridTrav = 256u * 8u * 256u / kTravThreads;  // persistent traversal blocks: every CU full
+#ifndef WFB_TRAV_BLOCKS_PER_CU
+#define WFB_TRAV_BLOCKS_PER_CU 7u
+#endif
+#ifndef WFB_ANY_BLOCKS_PER_CU
+#define WFB_ANY_BLOCKS_PER_CU 7u
+#endif
+// Persistent traversal blocks. Seven per CU, not the eight that fit: the any-hit kernel's 66 registers allow seven waves
+// per SIMD anyway (an eighth block per CU would start when the others end, and find nothing), and the closest-hit
+// kernel leaves a wave slot per SIMD to the other pipeline's logic / shading kernels (C4: 8 / 8, 8 / 7 and 7 / 7 are
+// equal within the +-0.4 % of repeated runs; 6 / 6 -1.4 %, 5 / 5 -2.6 %).
+constexpr unsigned kGridTrav = 256u * 8u * 256u / kTravThreads;  // (sizes the spill columns)
+constexpr unsigned kGridClosest = 256u * WFB_TRAV_BLOCKS_PER_CU * 256u / kTravThreads, kGridAny = 256u * WFB_ANY_BLOCKS_PER_CU * 256u / kTravThreads;
 // stack entries in LDS with 8 blocks per CU: what is left of 20 KB beside the first kWideTop wide nodes and the range slots (13 for 85 nodes)
 constexpr uint32_t kLdsEntriesMax = (160u * 1024u / 8u - kWideTop * 64u - kSlotBytes) / (kTravThreads * 4u);
 // a ray stacks at most three items per level of the wide tree; deeper trees than this stay with the one-kernel LBVH variant
@@ -955,7 +966,7 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
             grid_shade = std::min(grid, (unsigned)(per_cu * cus));
     }
     if (wfb_ray_positions(n, P.n_light) >= kMaxRayIds) return hipErrorInvalidValue;
-    const unsigned grid_trav = kGridTrav;
+    const unsigned grid_closest = kGridClosest, grid_any = kGridAny;
     if (stack_entries > kWideStackCap || !bvh.wide || (uint64_t)bvh.n + bvh.n_wide > (1ull << 24)) return hipErrorInvalidValue;  // wfb_supports()
     const uint32_t n_top = std::min(bvh.n_wide, kWideTop);
     uint32_t idx_bits = 1;
@@ -1002,27 +1013,29 @@ hipError_t wavefront_bvh_render(const Params &P, const float4 *blob, const Bvh &
             if ((e = hipMemsetAsync(&counters[1 - cur], 0, 4, s)) != hipSuccess) return join(e);
             if ((e = hipMemsetAsync(&counters[2], 0, 16, s)) != hipSuccess) return join(e);  // shade count, both fetch heads, shadow-ray count
             if (stats)
-                hipLaunchKernelGGL((WFB_TRAV<false, true>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[cur], (const float4 *)nullptr,
+                hipLaunchKernelGGL((WFB_TRAV<false, true>), dim3(grid_closest), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[cur], (const float4 *)nullptr,
                                    (const uint32_t *)nullptr, &counters[3], A.hit_leaf, (uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, stats, lds_entries, A.spill, idx_bits, n_top);
             else
-                hipLaunchKernelGGL((WFB_TRAV<false, false>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[cur], (const float4 *)nullptr,
+                hipLaunchKernelGGL((WFB_TRAV<false, false>), dim3(grid_closest), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[cur], (const float4 *)nullptr,
                                    (const uint32_t *)nullptr, &counters[3], A.hit_leaf, (uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
                                    (unsigned long long *)nullptr, lds_entries, A.spill, idx_bits, n_top);
             hipLaunchKernelGGL(wfb_logic, dim3(grid), dim3(256), 0, s, P, blob, bvh, A.Q[cur],
                                (const int *)A.hit_leaf, A.Q[1 - cur], A.Q[2], sums, A.ids, &counters[5]);
             if (stats)
-                hipLaunchKernelGGL((WFB_TRAV<true, true>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[2], blob,
+                hipLaunchKernelGGL((WFB_TRAV<true, true>), dim3(grid_any), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[2], blob,
                                    (const uint32_t *)(counters + 256), &counters[4], (int *)nullptr, A.occ, (const uint32_t *)A.ids, (const uint32_t *)&counters[5],
                                    stats, lds_entries, A.spill, idx_bits, n_top, P.light_off, P.n_light);
             else
-                hipLaunchKernelGGL((WFB_TRAV<true, false>), dim3(grid_trav), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[2], blob,
+                hipLaunchKernelGGL((WFB_TRAV<true, false>), dim3(grid_any), dim3(kTravThreads), stack_bytes, s, bvh, A.Q[2], blob,
                                    (const uint32_t *)(counters + 256), &counters[4], (int *)nullptr, A.occ, (const uint32_t *)A.ids, (const uint32_t *)&counters[5],
                                    (unsigned long long *)nullptr, lds_entries, A.spill, idx_bits, n_top, P.light_off, P.n_light);
             hipLaunchKernelGGL(wfb_shade, dim3(grid_shade), dim3(256), 0, s, P, blob, A.Q[2], (const uint32_t *)A.occ,
                                A.Q[1 - cur], sums);
         }
         cur = 1 - cur;
-        if ((it & 15u) == 15u) {
+        // The host looks at the queue counts every 16 rounds at first (a look drains the launch pipeline), every 4 once a
+        // 5-deep path's rounds are through: an empty round still costs 0.25 ms of launches (C4: 16 rounds per step).
+        if ((it & 15u) == 15u || (it >= 11u && (it & 3u) == 3u)) {
             uint32_t left[2] = {0, 0};
             for (uint32_t g = 0; g < n_groups; ++g)
                 if (!G[g].done && (e = hipMemcpyAsync(&left[g], &G[g].counters[cur], 4, hipMemcpyDeviceToHost, G[g].st)) != hipSuccess) return join(e);
