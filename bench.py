@@ -443,8 +443,9 @@ def main():
                             for k in ("closest", "any")},
                 "valu_fp32": {"achieved_tflops": round(achieved, 3), "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
                               "note": "sphere / plane tests and shading only: the cost table of SURVEY §8d prices no box tests"},
-                "limiter": "valu_issue (PMC: the traversal kernels keep every SIMD's vector ALU busy at 61-66 % active lanes, "
-                           "DESIGN.md §3; the byte roofline says how far the fetch path is from the L2's rate, not what limits the step)",
+                "limiter": "valu_issue + fetch latency (PMC: a vector instruction in flight on every SIMD cycle of the traversal kernels at 60-61 % "
+                           "active lanes; sensitivity runs: more issue work and fewer resident waves both slow the step, DESIGN.md §3; "
+                           "the byte roofline says how far the fetch path is from the L2's rate, not what limits the step)",
                 "note": "rank 0's GPU: algorithmic bytes of a step (64 B per 4-wide BVH node visited outside the LDS-resident first levels, "
                         "16 B per sphere fetched, 16 B per aux row, ray records, queue entries read and written by the logic / shading kernels) "
                         "/ duration of the step's kernels from HIP events on the launch stream, against the aggregate L2 rate of "
