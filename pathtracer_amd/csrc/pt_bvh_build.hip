@@ -137,8 +137,8 @@ __global__ void k_leaf_boxes(const float4 *__restrict__ sph_sorted, const float4
 // A better tree over the same Morton order than the radix tree: the clusters (at first the spheres) stand in Morton
 // order; every cluster looks at its `radius` neighbours on either side for the one whose union box with its own has
 // the smallest surface, mutual nearest neighbours are merged into a new node, the rest stay, the array is compacted
-// and the pass repeats until one cluster is left. The pair with the globally smallest surface is always mutual (ties
-// go to the lower position on both sides), so every pass merges at least one pair. Nodes are numbered downwards from
+// and the pass repeats until one cluster is left. The smallest pair of all is always mutual (k_ploc_nearest orders the
+// pairs totally), so every pass merges at least one pair. Nodes are numbered downwards from
 // n - 2 in the order they are made, so that the last one, the root, is node 0 as in the radix tree.
 __device__ __forceinline__ float union_area(float4 alo, float4 ahi, float4 blo, float4 bhi) {
     const float dx = fmaxf(ahi.x, bhi.x) - fminf(alo.x, blo.x), dy = fmaxf(ahi.y, bhi.y) - fminf(alo.y, blo.y),
@@ -158,7 +158,17 @@ __global__ void k_ploc_nearest(int count, int radius, const int *__restrict__ cl
         if (j == i) continue;
         const int bj = cl[j];
         const float a = union_area(alo, ahi, lo[bj], hi[bj]);  // symmetric in its arguments, bit for bit
-        if (a < best) best = a, best_j = j;                     // ties: the lower position
+        // Pairs are ordered by (surface, not an aligned pair {2k, 2k+1}, lower position, upper position) — a total
+        // order on unordered pairs, so the smallest pair of all is the choice of both its members. The aligned-pair
+        // rule matters for runs of identical boxes (coincident spheres): they pair off and the subtree stays log-deep,
+        // where "lowest position wins" merged one pair per pass into a chain (depth 70 for 250 coincident spheres).
+        bool better = a < best;
+        if (a == best) {
+            const int t_new = (i ^ 1) == j ? 0 : 1, t_old = (i ^ 1) == best_j ? 0 : 1;
+            const int lo_new = min(i, j), hi_new = max(i, j), lo_old = min(i, best_j), hi_old = max(i, best_j);
+            better = t_new != t_old ? t_new < t_old : (lo_new != lo_old ? lo_new < lo_old : hi_new < hi_old);
+        }
+        if (better) best = a, best_j = j;
     }
     nearest[i] = best_j;
 }
@@ -439,63 +449,74 @@ hipError_t bvh_build(const float4 *d_sph, const float4 *d_aux, uint32_t n, BvhBu
                                       (uint32_t *)idx_s.p, n, 0, 30, st));
     hipLaunchKernelGGL(k_gather, dim3(g), dim3(bs), 0, st, d_sph, d_aux, (const uint32_t *)idx_s.p, n, out.sph_sorted,
                        out.aux_sorted);
-    hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(bs), 0, st, (const uint32_t *)codes_s.p, N, (int *)left.p, (int *)right.p,
-                       (int *)parent.p);
-    BVH_TRY(hipMemsetAsync(ready_a.p, 0, (size_t)n_nodes * 4, st));
-    hipLaunchKernelGGL(k_leaf_boxes, dim3(g), dim3(bs), 0, st, out.sph_sorted, out.aux_sorted, N, (float4 *)lo.p, (float4 *)hi.p,
-                       (int *)ready_a.p);
-    if (bvh_builder_is_ploc()) {
-        // the radix tree's left / right arrays are replaced; everything after this (refit, packing, collapse) is unchanged
-        Tmp cl_a, cl_b, nearest, keep, keep_off, merge, merge_off, scan_tmp;
-        for (Tmp *t : {&cl_a, &cl_b, &nearest, &keep, &keep_off, &merge, &merge_off}) BVH_TRY(hipMalloc(&t->p, (size_t)n * 4));
-        size_t scan_bytes = 0;
-        BVH_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (int *)keep.p, (int *)keep_off.p, 0, (size_t)n, rocprim::plus<int>(), st));
-        BVH_TRY(hipMalloc(&scan_tmp.p, scan_bytes ? scan_bytes : 4));
-        hipLaunchKernelGGL(k_ploc_init, dim3(g), dim3(bs), 0, st, N, (int *)cl_a.p);
-        const int radius = bvh_ploc_radius();
-        int count = N, node_top = N - 2;
-        for (int pass = 0; count > 1; ++pass) {
-            if (pass > N) return hipErrorUnknown;  // (every pass merges at least one pair)
-            const unsigned gc = ((unsigned)count + bs - 1) / bs;
-            hipLaunchKernelGGL(k_ploc_nearest, dim3(gc), dim3(bs), 0, st, count, radius, (const int *)cl_a.p, (const float4 *)lo.p,
-                               (const float4 *)hi.p, (int *)nearest.p);
-            hipLaunchKernelGGL(k_ploc_flags, dim3(gc), dim3(bs), 0, st, count, (const int *)nearest.p, (int *)keep.p, (int *)merge.p);
-            BVH_TRY(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, (int *)keep.p, (int *)keep_off.p, 0, (size_t)count,
-                                            rocprim::plus<int>(), st));
-            BVH_TRY(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, (int *)merge.p, (int *)merge_off.p, 0, (size_t)count,
-                                            rocprim::plus<int>(), st));
-            hipLaunchKernelGGL(k_ploc_merge, dim3(gc), dim3(bs), 0, st, count, N, node_top, (const int *)cl_a.p, (const int *)nearest.p,
-                               (const int *)keep.p, (const int *)keep_off.p, (const int *)merge.p, (const int *)merge_off.p,
-                               (float4 *)lo.p, (float4 *)hi.p, (int *)left.p, (int *)right.p, (int *)cl_b.p);
-            int last[4] = {0, 0, 0, 0};
-            BVH_TRY(hipMemcpyAsync(&last[0], (int *)keep_off.p + count - 1, 4, hipMemcpyDeviceToHost, st));
-            BVH_TRY(hipMemcpyAsync(&last[1], (int *)keep.p + count - 1, 4, hipMemcpyDeviceToHost, st));
-            BVH_TRY(hipMemcpyAsync(&last[2], (int *)merge_off.p + count - 1, 4, hipMemcpyDeviceToHost, st));
-            BVH_TRY(hipMemcpyAsync(&last[3], (int *)merge.p + count - 1, 4, hipMemcpyDeviceToHost, st));
+    // The tree (radix tree, or PLOC when asked for), the leaf boxes and the bottom-up refit. A PLOC tree can come out
+    // deeper than the traversal stacks allow (concentric spheres of different radii chain: each pass merges the two
+    // smallest); the radix tree, whose depth is bounded by the key length, is built instead then.
+    int depth = 0;
+    for (int attempt = 0;; ++attempt) {
+        const bool ploc = bvh_builder_is_ploc() && attempt == 0;
+        hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(bs), 0, st, (const uint32_t *)codes_s.p, N, (int *)left.p, (int *)right.p,
+                           (int *)parent.p);
+        BVH_TRY(hipMemsetAsync(ready_a.p, 0, (size_t)n_nodes * 4, st));
+        hipLaunchKernelGGL(k_leaf_boxes, dim3(g), dim3(bs), 0, st, out.sph_sorted, out.aux_sorted, N, (float4 *)lo.p, (float4 *)hi.p,
+                           (int *)ready_a.p);
+        if (ploc) {
+            // the radix tree's left / right arrays are replaced; everything after this (refit, packing, collapse) is unchanged
+            Tmp cl_a, cl_b, nearest, keep, keep_off, merge, merge_off, scan_tmp;
+            for (Tmp *t : {&cl_a, &cl_b, &nearest, &keep, &keep_off, &merge, &merge_off}) BVH_TRY(hipMalloc(&t->p, (size_t)n * 4));
+            size_t scan_bytes = 0;
+            BVH_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (int *)keep.p, (int *)keep_off.p, 0, (size_t)n, rocprim::plus<int>(), st));
+            BVH_TRY(hipMalloc(&scan_tmp.p, scan_bytes ? scan_bytes : 4));
+            hipLaunchKernelGGL(k_ploc_init, dim3(g), dim3(bs), 0, st, N, (int *)cl_a.p);
+            const int radius = bvh_ploc_radius();
+            int count = N, node_top = N - 2;
+            for (int pass = 0; count > 1; ++pass) {
+                if (pass > N) return hipErrorUnknown;  // (every pass merges at least one pair)
+                const unsigned gc = ((unsigned)count + bs - 1) / bs;
+                hipLaunchKernelGGL(k_ploc_nearest, dim3(gc), dim3(bs), 0, st, count, radius, (const int *)cl_a.p, (const float4 *)lo.p,
+                                   (const float4 *)hi.p, (int *)nearest.p);
+                hipLaunchKernelGGL(k_ploc_flags, dim3(gc), dim3(bs), 0, st, count, (const int *)nearest.p, (int *)keep.p, (int *)merge.p);
+                BVH_TRY(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, (int *)keep.p, (int *)keep_off.p, 0, (size_t)count,
+                                                rocprim::plus<int>(), st));
+                BVH_TRY(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, (int *)merge.p, (int *)merge_off.p, 0, (size_t)count,
+                                                rocprim::plus<int>(), st));
+                hipLaunchKernelGGL(k_ploc_merge, dim3(gc), dim3(bs), 0, st, count, N, node_top, (const int *)cl_a.p, (const int *)nearest.p,
+                                   (const int *)keep.p, (const int *)keep_off.p, (const int *)merge.p, (const int *)merge_off.p,
+                                   (float4 *)lo.p, (float4 *)hi.p, (int *)left.p, (int *)right.p, (int *)cl_b.p);
+                int last[4] = {0, 0, 0, 0};
+                BVH_TRY(hipMemcpyAsync(&last[0], (int *)keep_off.p + count - 1, 4, hipMemcpyDeviceToHost, st));
+                BVH_TRY(hipMemcpyAsync(&last[1], (int *)keep.p + count - 1, 4, hipMemcpyDeviceToHost, st));
+                BVH_TRY(hipMemcpyAsync(&last[2], (int *)merge_off.p + count - 1, 4, hipMemcpyDeviceToHost, st));
+                BVH_TRY(hipMemcpyAsync(&last[3], (int *)merge.p + count - 1, 4, hipMemcpyDeviceToHost, st));
+                BVH_TRY(hipStreamSynchronize(st));
+                const int kept = last[0] + last[1], merged = last[2] + last[3];
+                if (merged < 1 || kept != count - merged || node_top - merged < -1) return hipErrorUnknown;
+                count = kept;
+                node_top -= merged;
+                std::swap(cl_a.p, cl_b.p);
+            }
+            if (node_top != -1) return hipErrorUnknown;  // n - 1 nodes made, the last of them node 0
             BVH_TRY(hipStreamSynchronize(st));
-            const int kept = last[0] + last[1], merged = last[2] + last[3];
-            if (merged < 1 || kept != count - merged || node_top - merged < -1) return hipErrorUnknown;
-            count = kept;
-            node_top -= merged;
-            std::swap(cl_a.p, cl_b.p);
         }
-        if (node_top != -1) return hipErrorUnknown;  // n - 1 nodes made, the last of them node 0
-        BVH_TRY(hipStreamSynchronize(st));
-    }
-    // bottom-up, one launch per level; the number of levels is the tree depth
-    int total = 0, depth = 0;
-    for (; total < N - 1; ++depth) {
-        if (depth > 4 * 64) return hipErrorUnknown;  // a level that completes no node: malformed tree
-        hipLaunchKernelGGL(k_copy_ready, dim3(gn), dim3(bs), 0, st, n_nodes, (const int *)ready_a.p, (int *)ready_b.p);
-        BVH_TRY(hipMemsetAsync(done.p, 0, 4, st));
-        hipLaunchKernelGGL(k_refit_level, dim3(g), dim3(bs), 0, st, N, (const int *)left.p, (const int *)right.p, (float4 *)lo.p,
-                           (float4 *)hi.p, (const int *)ready_a.p, (int *)ready_b.p, (int *)done.p);
-        int d = 0;
-        BVH_TRY(hipMemcpyAsync(&d, done.p, 4, hipMemcpyDeviceToHost, st));
-        BVH_TRY(hipStreamSynchronize(st));
-        if (d == 0) return hipErrorUnknown;
-        total += d;
-        std::swap(ready_a.p, ready_b.p);
+        // bottom-up, one launch per level; the number of levels is the tree depth
+        int total = 0;
+        depth = 0;
+        for (; total < N - 1; ++depth) {
+            if (ploc && depth > BVH_STACK) break;         // too deep already: no need to finish the refit
+            if (depth > 4 * 64) return hipErrorUnknown;  // a level that completes no node: malformed tree
+            hipLaunchKernelGGL(k_copy_ready, dim3(gn), dim3(bs), 0, st, n_nodes, (const int *)ready_a.p, (int *)ready_b.p);
+            BVH_TRY(hipMemsetAsync(done.p, 0, 4, st));
+            hipLaunchKernelGGL(k_refit_level, dim3(g), dim3(bs), 0, st, N, (const int *)left.p, (const int *)right.p, (float4 *)lo.p,
+                               (float4 *)hi.p, (const int *)ready_a.p, (int *)ready_b.p, (int *)done.p);
+            int d = 0;
+            BVH_TRY(hipMemcpyAsync(&d, done.p, 4, hipMemcpyDeviceToHost, st));
+            BVH_TRY(hipStreamSynchronize(st));
+            if (d == 0) return hipErrorUnknown;
+            total += d;
+            std::swap(ready_a.p, ready_b.p);
+        }
+        if (ploc && depth > BVH_STACK) continue;
+        break;
     }
     // node units over the root box (internal node 0): its centre is the origin, its half-extents are 1024 units
     float4 root_lo, root_hi;

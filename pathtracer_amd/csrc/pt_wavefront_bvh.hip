@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
             auto key = [&](uint4 q) {
                 float t;
                 const bool hit = slot_hit(br, q, bound, t);
-                uint32_t k = (__float_as_uint(t) & ~idx_mask) | q.w;
+                uint32_t k = (__float_as_uint(t) & (~idx_mask & 0x7fffffffu)) | q.w;  // (t >= 0; the sign is masked so that a -0 cannot pose as the farthest key)
                 asm volatile("" : "+v"(k));
                 return hit ? k : kKeyNone;
             };

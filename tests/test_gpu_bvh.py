@@ -69,9 +69,7 @@ def test_ploc_builder_gives_the_same_hits_and_the_same_image(hip, scene20k, monk
         assert np.array_equal(hip_renderer.render_accum(s, seed=9, flags=_abi.FLAG_WAVEFRONT), img_radix), radius
 
 
-def test_bvh_tie_rule_and_duplicates(hip):
-    """Coincident spheres (identical centre and radius, many of them, so identical Morton codes):
-    the lowest scene order must win, as Iterator::min_by keeps the first minimum."""
+def _coincident_scene():
     from pathtracer_amd import Scene
     from pathtracer_amd.scene import SPHERE_DTYPE
     s = Scene()
@@ -93,6 +91,15 @@ def test_bvh_tie_rule_and_duplicates(hip):
     rd = np.tile(np.array([0.5, 0.25, 12.0], np.float32) / np.linalg.norm([0.5, 0.25, 12.0]), (64, 1))
     rd[1:] += rng.normal(0, 0.02, (63, 3)).astype(np.float32)
     rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    return s, sp, ro, rd
+
+
+@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
+def test_bvh_tie_rule_and_duplicates(hip, monkeypatch, builder):
+    """Coincident spheres (identical centre and radius, many of them, so identical Morton codes):
+    the lowest scene order must win, as Iterator::min_by keeps the first minimum. Both tree builders."""
+    monkeypatch.setenv("HIPPT_BVH_BUILDER", builder)
+    s, sp, ro, rd = _coincident_scene()
     t_b, _, i_b = hip.intersect(s, ro, rd)
     t_v, _, i_v = hip.intersect_bvh(s, ro, rd)
     assert np.array_equal(i_b, i_v) and np.array_equal(t_b, t_v)

@@ -69,6 +69,22 @@ def test_lbvh_paths_equal_brute_force(name):
         assert abs(got.sum(dtype=np.float64) - tot) <= 1e-3 * tot
 
 
+@pytest.mark.parametrize("name", ["far from the origin", "flat slab", "needle", "mixed radii", "huge scene", "64 spheres"])
+def test_ploc_tree_paths_equal_brute_force(name, monkeypatch):
+    """The same comparison with the opt-in PLOC tree (HIPPT_BVH_BUILDER=ploc): other boxes, other depth, same image."""
+    from pathtracer_amd import _abi, hip_renderer
+    s = cloud(**CASES[name])
+    b = hip_renderer.render_accum(s, seed=3, flags=_abi.FLAG_NO_BVH)
+    monkeypatch.setenv("HIPPT_BVH_BUILDER", "ploc")
+    scale = np.maximum(np.abs(b).max(axis=2), 1e-3 * b.max())
+    for flags in (0, _abi.FLAG_MEGAKERNEL):
+        got = hip_renderer.render_accum(s, seed=3, flags=flags)
+        e = np.abs(got.astype(np.float64) - b).max(axis=2) / scale
+        assert np.isfinite(got).all() and np.quantile(e, 0.98) < 1e-5, (name, flags, np.quantile(e, [0.5, 0.98, 1.0]))
+        tot = b.sum(dtype=np.float64)
+        assert abs(got.sum(dtype=np.float64) - tot) <= 1e-3 * tot
+
+
 def test_more_lights_than_the_queue_pipeline_takes():
     """100 lights: the jump-ahead table of the queue pipeline holds 96, so the library renders the scene with the
     one-kernel LBVH variant by itself (and refuses an explicit HIPPT_FLAG_WAVEFRONT); image == brute force."""
