@@ -402,21 +402,11 @@ __global__ __launch_bounds__(kTravThreads, WFB_TRAV_MIN_BLOCKS) void wfb_travers
         if (has) {
         // ---- one item: fetch ----
 #ifdef WFB_DUMMY_VALU
-        {   // sensitivity experiment: extra full-rate VALU work per trip
+        {   // sensitivity experiment (profiles/r03_c4_ab_log.txt): -DWFB_DUMMY_VALU=n adds n independent full-rate instructions per trip
             float d0 = t_max, d1 = t_max;
 #pragma unroll
             for (int i = 0; i < WFB_DUMMY_VALU / 2; ++i) asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1" : "+v"(d0), "+v"(d1));
             asm volatile("" ::"v"(d0), "v"(d1));
-        }
-#endif
-#ifdef WFB_DUMMY_LOAD
-        {   // sensitivity experiment: one more 16-byte gather per trip (the item's own first row again)
-            const uint32_t u_ = cur & idx_mask;
-            const uint4 *p_ = u_ < bvh.n ? reinterpret_cast<const uint4 *>(bvh.sph) + u_ : bvh.wide + (size_t)(u_ - bvh.n) * 4u;
-            uint4 dq;
-            asm volatile("global_load_dwordx4 %0, %1, off offset:0 sc0" : "=v"(dq) : "v"(p_) : "memory");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("" ::"v"(dq));
         }
 #endif
         const uint32_t u = cur & idx_mask;
