@@ -228,8 +228,8 @@ int hippt_set_scene(hippt_context *ctx, const hippt_scene *scene);
  * path queues in device memory that the context allocates on first use and holds until hippt_destroy:
  * up to 96 GiB for large images and sample counts (2^28 paths in flight), less when the GPU cannot
  * spare it (it then runs fewer concurrent sample streams: slower, same image; the stream count that fitted is
- * remembered by the context); with a build that runs two pipeline groups (WFB_GROUPS = 2; the default is one) it
- * also launches on a second internal stream forked from / joined to `stream`. One call may cover any number of
+ * remembered by the context); it runs two pipeline groups (WFB_GROUPS = 2, the default since the end of round 3) and
+ * therefore also launches on a second internal stream forked from / joined to `stream`. One call may cover any number of
  * samples: launches are cut at 4 096 samples per pixel and their sums added to d_accum one by one. This is the hot path
  * (src/renderer.rs:163-182 + 237-353 for every pixel). */
 int hippt_render_accum_device(hippt_context *ctx, const hippt_options *opts,
